@@ -1,0 +1,59 @@
+"""Helpers shared by the parity tests: load a golden fixture, build oracles from it."""
+import os
+
+import numpy as np
+import torch
+
+from oracle.torch_oracle import CondNet, PathConfig, Trainer, set_dropout
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky"]
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        d = dict(zip(("B", "G", "P", "T", "Dt", "Dp", "E", "H", "L", "n_critic"),
+                     (int(v) for v in self.z["dims"])))
+        self.dims = d
+        self.slope = float(self.z["slope"])
+
+    def cfg(self, optimizer="rms_prop") -> PathConfig:
+        d = self.dims
+        return PathConfig(n_genes=d["G"], latent_dims=d["L"], embedding_dims=d["E"], hidden_dims=d["H"],
+                          text_dims=d["Dt"], patch_dims=d["Dp"], negative_slope=self.slope, dropout=0.0,
+                          optimizer=optimizer, n_critic=d["n_critic"])
+
+    def t(self, key):
+        return torch.from_numpy(np.asarray(self.z[key]))
+
+    def group(self, prefix):
+        p = prefix + "/"
+        return {k[len(p):]: self.z[k] for k in self.z.files if k.startswith(p)}
+
+    def state(self, prefix):
+        return {k: torch.from_numpy(v) for k, v in self.group(prefix).items()}
+
+    def inputs(self):
+        return tuple(self.t("in/" + k) for k in ("x", "text", "text_pad", "patches", "patch_pad"))
+
+    def cond(self):
+        x, text, text_pad, patches, patch_pad = self.inputs()
+        return (patches, patch_pad, text, text_pad)
+
+    def trainer(self, optimizer="rms_prop") -> Trainer:
+        cfg = self.cfg(optimizer)
+        gen, disc = CondNet("generator", cfg), CondNet("discriminator", cfg)
+        gen.load_state_dict(self.state("init_gen"), strict=True)
+        disc.load_state_dict(self.state("init_disc"), strict=True)
+        set_dropout(gen, 0.0)
+        set_dropout(disc, 0.0)
+        return Trainer(cfg, gen, disc)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(np.abs(b).max(), 1e-30)
+    return float(np.abs(a - b).max() / den)
