@@ -1,0 +1,125 @@
+"""Pin oracle/numpy_oracle.py (closed-form forward + hand-derived backward, float64) against
+(1) golden vectors of the real reference and (2) oracle #1 (torch autograd) on other shapes."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import FIXTURES, Golden, comparable, rel_err
+from oracle import numpy_oracle as no
+from oracle.torch_oracle import CondNet, PathConfig, Trainer, set_dropout, synthetic_batch
+
+TOL = 2e-5   # fp64 closed form vs fp32 reference outputs
+
+
+def _np_inputs(g):
+    x, text, text_pad, patches, patch_pad = (t.numpy() for t in g.inputs())
+    return x.astype(np.float64), (patches.astype(np.float64), patch_pad, text.astype(np.float64), text_pad)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_forward_vs_golden(name):
+    g = Golden(name)
+    pd = no.params_from_state(g.group("init_disc"))
+    pg = no.params_from_state(g.group("init_gen"))
+    x, cond = _np_inputs(g)
+    c, cache = no.cond_fwd(pd, *cond)
+    ref = g.group("disc_fwd")
+    assert rel_err(cache["tok"], ref["text_enc"]) < TOL
+    assert rel_err(cache["seq"][:, 1:], ref["patch_emb"]) < TOL
+    assert rel_err(cache["xs"][1], ref["enc_layer0"]) < TOL
+    assert rel_err(cache["enc"], ref["enc_layer1"]) < TOL
+    assert rel_err(cache["t2i"], ref["t2i"]) < TOL
+    assert rel_err(cache["i2t"], ref["i2t"]) < TOL
+    out, ch = no.head_fwd(pd, "discriminator", x, c, g.slope)
+    assert rel_err(ch["h1"], ref["mlp_pre0"]) < TOL
+    assert rel_err(out, ref["out"]) < TOL
+    xg = no.net_forward(pg, "generator", g.z["gen_fwd/z"].astype(np.float64), *cond, slope=g.slope)
+    assert rel_err(xg, g.z["gen_fwd/out"]) < TOL
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_critic_iteration_vs_golden(name):
+    g = Golden(name)
+    pd = no.params_from_state(g.group("init_disc"))
+    pg = no.params_from_state(g.group("init_gen"))
+    x, cond = _np_inputs(g)
+    losses, grads, x_fake, grad_x = no.critic_iteration_grads(
+        pg, pd, x, g.z["critic1/z"].astype(np.float64), g.z["critic1/alpha"].astype(np.float64), cond, slope=g.slope)
+    los = g.z["critic1/losses"]
+    assert rel_err([losses["total"], losses["d_loss"], losses["d_real"], losses["d_fake"]], los) < TOL
+    assert rel_err(grad_x, g.z["critic1/grad_x_hat"]) < TOL
+    ref = g.group("critic1/grad")
+    assert set(ref) == set(grads)
+    for n, r in ref.items():
+        assert rel_err(grads[n], r) < 5e-5, n
+    tot, coef = no.clip_coef(grads, 10.0)
+    assert abs(tot - float(g.z["critic1/grad_total_norm"])) < 1e-5 * tot
+    opt = no.Optim("rms_prop", 5e-4)
+    opt.step(pd, {n: v * coef for n, v in grads.items()})
+    for n, r in g.group("critic1/post_disc").items():
+        keep = comparable(n, pd[n], g.dims["E"])[::3]
+        # first RMSprop step == -lr*g/(0.1|g|+1e-8): entries with |g|~1e-7 amplify fp32-vs-fp64 noise
+        assert rel_err(pd[n].reshape(-1)[::3][keep], r[keep]) < 1e-3, n
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_generator_iteration_vs_golden(name):
+    g = Golden(name)
+    pd = no.params_from_state(g.group("init_disc"))
+    pg = no.params_from_state(g.group("init_gen"))
+    x, cond = _np_inputs(g)
+    g_loss, grads, _ = no.generator_iteration_grads(pg, pd, g.z["gen1/z"].astype(np.float64), cond, slope=g.slope)
+    assert abs(g_loss - float(g.z["gen1/loss"])) < 1e-5 * max(1, abs(g_loss))
+    ref = g.group("gen1/grad")
+    assert set(ref) == set(grads)
+    for n, r in ref.items():
+        assert rel_err(grads[n], r) < 5e-5, n
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("opt", ["rms_prop", "adam", "adamw"])
+def test_full_step_vs_golden(name, opt):
+    g = Golden(name)
+    pd = no.params_from_state(g.group("init_disc"))
+    pg = no.params_from_state(g.group("init_gen"))
+    x, cond = _np_inputs(g)
+    zs = g.z[f"step_{opt}/z"].astype(np.float64)
+    al = g.z[f"step_{opt}/alpha"].astype(np.float64)
+    losses, g_loss = no.train_step(pg, pd, no.Optim(opt, 5e-4), no.Optim(opt, 5e-4), x, cond, list(zs), list(al), slope=g.slope)
+    assert rel_err([losses["d_loss"], losses["d_real"], losses["d_fake"]], g.z[f"step_{opt}/d_batch_loss"]) < 1e-4
+    assert abs(g_loss - float(g.z[f"step_{opt}/gen_loss"])) < 1e-4
+    stride = 1 if opt == "rms_prop" else 5
+    # RMSprop/Adam normalise tiny gradients to +-lr steps: compare the UPDATE relative to lr
+    for role, p in (("gen", pg), ("disc", pd)):
+        init = g.group(f"init_{role}")
+        for n, r in g.group(f"step_{opt}/post_{role}").items():
+            keep = comparable(n, p[n], g.dims["E"])[::stride]
+            a = p[n].reshape(-1)[::stride][keep]
+            assert np.abs(a - r.reshape(-1)[keep]).max() < 2e-4 * max(np.abs(r).max(), 1e-3) + 1e-6, (role, n)
+
+
+def test_vs_torch_autograd_other_shape():
+    """T=4 with padded tokens, padded patches, nh=4 (dh=4): closed form == autograd."""
+    torch.manual_seed(7)
+    cfg = PathConfig(n_genes=23, latent_dims=6, embedding_dims=16, hidden_dims=12, text_dims=10, patch_dims=14,
+                     dropout=0.0, negative_slope=0.1)
+    tr = Trainer(cfg)
+    set_dropout(tr.gen, 0.0); set_dropout(tr.disc, 0.0)
+    tr.gen.double(); tr.disc.double()
+    x, text, text_pad, patches, patch_pad = (t.double() if t.dtype != torch.bool else t
+                                              for t in synthetic_batch(cfg, 7, 5, 4, seed=3, pad_patches=True, pad_text=True))
+    cond = (patches, patch_pad, text, text_pad)
+    z = torch.randn(7, 6, dtype=torch.float64); alpha = torch.rand(7, 1, dtype=torch.float64)
+    pg = no.params_from_state(tr.gen.state_dict()); pd = no.params_from_state(tr.disc.state_dict())
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    npc = tuple(t.numpy() for t in cond)
+    losses, grads, _, grad_x = no.critic_iteration_grads(pg, pd, x.numpy(), z.numpy(), alpha.numpy(), npc, slope=0.1)
+    assert abs(losses["total"] - r["total"].item()) < 1e-10
+    assert rel_err(grad_x, r["grad_x_hat"].detach()) < 1e-10
+    for n, v in grads.items():
+        assert rel_err(v, r["grads"][n]) < 1e-8, n
+    rg = tr.generator_iteration(z, cond, apply=False)
+    g_loss, ggr, _ = no.generator_iteration_grads(pg, pd, z.numpy(), npc, slope=0.1)
+    assert abs(g_loss - rg["g_loss"].item()) < 1e-10
+    for n, v in ggr.items():
+        assert rel_err(v, rg["grads"][n]) < 1e-8, n
