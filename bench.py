@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WGAN-GP samples/sec of the full train() step (n_critic=5, 5 000 genes,
+256 patch tokens x 1024 + 1 text token x 512, B=256 per GPU) - BASELINE.json `metric`, config 3 /
+config 4 (DP, weak scaling: fixed per-GPU batch).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the env), RCCL ("nccl" backend) all-reduce
+of the flat gradient buffer per optimiser step.  Rank 0 prints ONE JSON line.
+
+A "step" = one WGAN_GP.train() (R:463-477): 5 x {G fwd, D(fake), D(real), GP with double backward,
+backward, clip 10, RMSprop step} + {G fwd, D fwd, backward, clip 2, RMSprop step}, dropout 0.1 in
+the encoder layers exactly as the reference's train() mode, synthetic N(0,1) inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters; dense, no sparsity)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU minibatch (config 3: 256)")
+    ap.add_argument("--genes", type=int, default=5000)
+    ap.add_argument("--patches", type=int, default=256)
+    ap.add_argument("--tokens", type=int, default=1)
+    ap.add_argument("--text-dims", type=int, default=512)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
+    bounded sample: the same workload at a smaller minibatch, 1 warm-up + 2 timed train() steps."""
+    from oracle.torch_oracle import PathConfig, Trainer, synthetic_batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    cfg = PathConfig(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
+    Bc = args.cpu_batch
+    torch.manual_seed(42)
+    tr = Trainer(cfg)
+    x, text, text_pad, patches, patch_pad = synthetic_batch(cfg, Bc, args.patches, args.tokens, seed=42)
+    def step():
+        zs = [torch.randn(Bc, cfg.latent_dims) for _ in range(cfg.n_critic + 1)]
+        al = [torch.rand(Bc, 1) for _ in range(cfg.n_critic)]
+        tr.train_step(x, text, text_pad, patches, patch_pad, zs, al)
+    step()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=round(Bc * n / dt, 3), unit="samples/s", cores=cores, kind="port",
+                sample=f"oracle/torch_oracle.py (stock torch CPU modules, fp32), same workload at minibatch {Bc}: "
+                       f"1 warm-up + {n} timed train() steps, {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gemm_gan_amd as gga
+    G, B, P, T = args.genes, args.batch, args.patches, args.tokens
+    H = E = Lz = 256
+    torch.manual_seed(42)                       # identical initial weights on every rank
+    w = gga.WGAN_GP(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
+                    optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="")
+    w.build_WGAN_GP()
+    w.init_train()
+    w.reserve(B, P, T)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)   # per-rank shard of the global minibatch
+    x = torch.randn(B, G, device=dev, generator=g)
+    patches = torch.randn(B, P, 1024, device=dev, generator=g)
+    text = torch.randn(B, T, args.text_dims, device=dev, generator=g)
+    patch_pad = torch.zeros(B, P, dtype=torch.bool, device=dev)
+    text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        w.train(x, text, text_pad, patches, patch_pad)
+    prof = (not args.no_profile) and rank == 0
+    sync()
+    if prof:
+        w.engine.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.train(x, text, text_pad, patches, patch_pad)
+    sync()
+    dt = time.perf_counter() - t0
+    rows = []
+    if prof:
+        rows = w.engine.profile_collect()
+        w.engine.profile(False)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    finite = bool(torch.isfinite(w.engine.flat[0]["w"]).all() and torch.isfinite(w.engine.flat[1]["w"]).all())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {"metric": "WGAN-GP samples/sec (n_critic=5, 5k-gene)", "value": round(value, 2), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), "
+                                      f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
+                                      f"n_critic=5, rms_prop, dropout {args.dropout}",
+                          "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count()},
+               "finite": finite,
+               "losses": {"d": float(w.d_batch_loss[0]), "g": float(w.g_batch_loss[0])}}
+        if rows:
+            rows = [r for r in rows if r["launches"] > 0]
+            dom = max(rows, key=lambda r: r["ms"])
+            tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            frac_m, frac_h = tf / PEAK_TFLOPS["f32"], gbs / PEAK_HBM_GBS
+            bound = "mfma" if frac_m >= frac_h else "hbm"
+            out["roofline"] = {"kernel": dom["name"], "bound": bound,
+                               "achieved": round(tf if bound == "mfma" else gbs, 2),
+                               "peak": PEAK_TFLOPS["f32"] if bound == "mfma" else PEAK_HBM_GBS,
+                               "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                               "frac": round(max(frac_m, frac_h), 4), "traffic": None,
+                               "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
+                               "share_of_step": round(dom["ms"] / (dt * 1e3), 3),
+                               "all_gemm_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),
+                                                     "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                                     "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows]}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as ex:  # pragma: no cover
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

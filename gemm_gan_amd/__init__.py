@@ -1,0 +1,11 @@
+"""gemm_gan_amd - MI355X-native WGAN-GP engine for GeMM-GAN's conditional generator/critic hot path.
+
+Public surface = the reference's own names (see model.py) + the low-level Engine wrapper.
+Importing this package does not need a GPU; constructing an Engine / building a WGAN_GP does, and
+fails loudly otherwise (no CPU fallback on the product path).
+"""
+from ._lib import LIB_PATH, build, load  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .model import WGAN_GP, WGAN_GP_model, discriminator, generator  # noqa: F401
+
+__all__ = ["Engine", "WGAN_GP", "WGAN_GP_model", "generator", "discriminator", "build", "load", "LIB_PATH"]

@@ -1,0 +1,109 @@
+"""ctypes binding of libgemmgan.so (C ABI in include/gemmgan.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the
+engine raises.  ``build()`` compiles it in-tree with hipcc for gfx950 (no GPU needed to build).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgemmgan.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ROLE_GENERATOR, ROLE_CRITIC = 0, 1
+OPT_KINDS = {"rms_prop": 0, "adam": 1, "adamw": 2}
+LOSS_D_REAL, LOSS_D_FAKE, LOSS_GP, LOSS_G, N_LOSSES = 0, 1, 2, 3, 8
+LAY_KC, LAY_KS = 0, 1
+
+
+class GGConfig(C.Structure):
+    _fields_ = [("n_genes", C.c_int32), ("latent_dims", C.c_int32), ("embedding_dims", C.c_int32),
+                ("hidden_dims", C.c_int32), ("text_dims", C.c_int32), ("patch_dims", C.c_int32),
+                ("n_heads", C.c_int32), ("n_layers", C.c_int32), ("negative_slope", C.c_float),
+                ("dropout", C.c_float), ("lr_d", C.c_float), ("lr_g", C.c_float), ("optimizer", C.c_int32),
+                ("gp_weight", C.c_float), ("clip_d", C.c_float), ("clip_g", C.c_float),
+                ("max_batch", C.c_int32), ("max_patches", C.c_int32), ("max_text_tokens", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class GGCond(C.Structure):
+    _fields_ = [("patches", C.c_void_p), ("patch_pad", C.c_void_p), ("text", C.c_void_p),
+                ("text_pad", C.c_void_p), ("B", C.c_int32), ("P", C.c_int32), ("T", C.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/gemmgan.h declares
+SYMBOLS = {
+    "gg_last_error": (C.c_char_p, []),
+    "gg_version": (C.c_char_p, []),
+    "gg_create": (C.c_int, [C.POINTER(GGConfig), C.POINTER(C.c_void_p)]),
+    "gg_destroy": (None, [C.c_void_p]),
+    "gg_param_count": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_param_name": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int]),
+    "gg_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gg_flat_numel": (C.c_int64, [C.c_void_p, C.c_int]),
+    "gg_bind_net": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gg_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "gg_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gg_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_int, C.c_void_p]),
+    "gg_critic_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
+    "gg_critic_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "gg_generator_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
+    "gg_generator_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "gg_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gg_set_lr": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "gg_set_dropout": (C.c_int, [C.c_void_p, C.c_float]),
+    "gg_set_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "gg_reset_optimizer_steps": (C.c_int, [C.c_void_p]),
+    "gg_get_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gg_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                               C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
+                               C.c_int, C.c_void_p]),
+    "gg_launch_count": (C.c_int64, [C.c_void_p]),
+    "gg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_profile_collect": (C.c_int, [C.c_void_p]),
+    "gg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gg_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip into gemm_gan_amd/libgemmgan.so for gfx950 (hipcc, in-tree)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libgemmgan.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP engine.  Raises (never falls back) when the library is absent or broken."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built "
+                          f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`). "
+                          "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("gemmgan: " + load().gg_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,977 @@
+// WGAN-GP step engine: parameter layout, workspace arena, forward / hand-written backward of the
+// conditioning stack (FiLM -> patch encoder -> CLS -> post-norm encoder layers -> two single-query
+// cross attentions), critic / generator MLP heads, closed-form gradient penalty with its double
+// backward, global-norm clip + optimiser.  Exposed through the C ABI of include/gemmgan.h.
+//
+// Reference: /root/reference/src/conditional_gan_cross_attention_with_film.py (R:), restated in
+// oracle/numpy_oracle.py whose decomposition this file follows line by line.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gemmgan.h"
+#include "gg_common.h"
+#include "kernels.h"
+
+namespace gg {
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+namespace {
+constexpr int MAXL = 8;
+
+struct ParamInfo {
+    std::string name;
+    long off = 0, numel = 0;
+    int ndim = 0;
+    int shape[3] = {0, 0, 0};
+};
+
+struct AttnP { long inw, inb, ow, ob; };
+struct LayerP { AttnP sa; long l1w, l1b, l2w, l2b, n1w, n1b, n2w, n2b; };
+
+struct Net {
+    int role = 0;
+    std::vector<ParamInfo> ps;
+    long total = 0;
+    long cls, film_w, film_b, te_w, te_b, pe_w, pe_b;
+    LayerP layer[MAXL];
+    AttnP t2i, i2t;
+    long w1, b1, w2, b2, w3, b3;
+    int V = 0, OUT = 0;            // first-layer non-conditioning width (L or G), output width (G or 1)
+    float *w = nullptr, *g = nullptr, *s1 = nullptr, *s2 = nullptr;
+    int step_t = 0;
+    float lr = 0.f;
+
+    long add(const std::string& name, int d0, int d1 = 0, int d2 = 0) {
+        ParamInfo p;
+        p.name = name;
+        p.ndim = d2 ? 3 : (d1 ? 2 : 1);
+        p.shape[0] = d0; p.shape[1] = d1; p.shape[2] = d2;
+        p.numel = (long)d0 * (d1 ? d1 : 1) * (d2 ? d2 : 1);
+        p.off = total;
+        total += (p.numel + 3) / 4 * 4;     // 16-byte aligned slots: vector loads on every weight
+        ps.push_back(p);
+        return p.off;
+    }
+};
+
+struct LayerActs {
+    float *qkv, *P, *ctx, *r1, *x1, *h, *r2, *x2, *st1, *st2;
+};
+struct CondActs {
+    int B = 0, R = 1, P = 0, T = 0;
+    uint32_t call = 0;
+    float drop = 0.f;
+    float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
+    uint8_t* mask;
+    LayerActs L[MAXL];
+    float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out;
+    float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
+    float* c;     // [R*B, E]
+};
+struct HeadActs {
+    float *a1, *a2, *out;   // [rows,H], [rows,H], [rows,OUT]
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+}  // namespace
+}  // namespace gg
+
+using namespace gg;
+
+struct gg_engine {
+    gg_config cfg;
+    int E, F, H, G, L, Dt, Dp, nh, nl, dh;
+    int maxB, maxP, maxT, maxS, maxR;
+    Net net[2];
+    float dropout = 0.f;
+    uint64_t seed = 0;
+    uint32_t call_counter = 0;
+    int64_t launches = 0;
+    // workspace
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    CondActs actsG, actsD;
+    HeadActs headG, headD;
+    float *X2;                 // [2B, G]: fake rows then real rows
+    float *c3;                 // [3B, E] conditioning rows for the critic head (fake, real, hat)
+    float *Pfr;                // [2B, H] x @ W1x^T for fake / real
+    float *dseed;              // [2B]
+    float *dA, *dB;            // [3B, H] scratch
+    float *dc;                 // [3B, E]
+    float *gp_g2, *gp_g1, *gp_g1s, *gp_grad, *gp_nrm2, *gp_coef, *gp_dg1, *gp_dg2;
+    float *dxfake;             // [B, G]
+    float *sumsq;              // [4]
+    // conditioning backward scratch
+    float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
+    float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
+    hipStream_t st = nullptr;
+    // live profiling
+    bool prof_on = false;
+    struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_next = 0;
+    struct ProfAgg { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::vector<ProfAgg> prof_agg;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------------
+void build_net(gg_engine* e, int role) {
+    Net& n = e->net[role];
+    n.role = role;
+    const int E = e->E, F = e->F, H = e->H, Dt = e->Dt, Dp = e->Dp;
+    n.V = role == GG_ROLE_GENERATOR ? e->L : e->G;
+    n.OUT = role == GG_ROLE_GENERATOR ? e->G : 1;
+    const std::string mlp = role == GG_ROLE_GENERATOR ? "generator" : "discriminator";
+    n.cls = n.add("patches_cls_token", 1, 1, E);
+    n.film_w = n.add("film_generator.weight", 2 * Dp, Dt);
+    n.film_b = n.add("film_generator.bias", 2 * Dp);
+    n.te_w = n.add("text_encoder.weight", E, Dt);
+    n.te_b = n.add("text_encoder.bias", E);
+    n.pe_w = n.add("patches_encoder.weight", E, Dp);
+    n.pe_b = n.add("patches_encoder.bias", E);
+    for (int l = 0; l < e->nl; ++l) {
+        const std::string p = "patches_transformer.layers." + std::to_string(l) + ".";
+        LayerP& L = n.layer[l];
+        L.sa.inw = n.add(p + "self_attn.in_proj_weight", 3 * E, E);
+        L.sa.inb = n.add(p + "self_attn.in_proj_bias", 3 * E);
+        L.sa.ow = n.add(p + "self_attn.out_proj.weight", E, E);
+        L.sa.ob = n.add(p + "self_attn.out_proj.bias", E);
+        L.l1w = n.add(p + "linear1.weight", F, E);
+        L.l1b = n.add(p + "linear1.bias", F);
+        L.l2w = n.add(p + "linear2.weight", E, F);
+        L.l2b = n.add(p + "linear2.bias", E);
+        L.n1w = n.add(p + "norm1.weight", E);
+        L.n1b = n.add(p + "norm1.bias", E);
+        L.n2w = n.add(p + "norm2.weight", E);
+        L.n2b = n.add(p + "norm2.bias", E);
+    }
+    auto attn = [&](const std::string& p, AttnP& a) {
+        a.inw = n.add(p + "in_proj_weight", 3 * E, E);
+        a.inb = n.add(p + "in_proj_bias", 3 * E);
+        a.ow = n.add(p + "out_proj.weight", E, E);
+        a.ob = n.add(p + "out_proj.bias", E);
+    };
+    attn("patch2text_attention.", n.t2i);
+    attn("text2patch_attention.", n.i2t);
+    n.w1 = n.add(mlp + ".0.0.weight", H, n.V + E);
+    n.b1 = n.add(mlp + ".0.0.bias", H);
+    n.w2 = n.add(mlp + ".1.0.weight", H, H);
+    n.b2 = n.add(mlp + ".1.0.bias", H);
+    n.w3 = n.add("final_layer.weight", n.OUT, H);
+    n.b3 = n.add("final_layer.bias", n.OUT);
+}
+
+void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
+    const long B = e->maxB, S = e->maxS, T = e->maxT, E = e->E, F = e->F, nh = e->nh;
+    const long RB = R * B;
+    c.gbpre = a.take<float>(B * 2 * e->Dp);
+    c.gb = a.take<float>(B * 2 * e->Dp);
+    c.tok = a.take<float>(B * T * E);
+    c.x0 = a.take<float>(B * S * E);
+    c.xrep = a.take<float>(RB * S * E);
+    c.tokrep = a.take<float>(RB * T * E);
+    c.mask = a.take<uint8_t>(B * S);
+    for (int l = 0; l < e->nl; ++l) {
+        LayerActs& L = c.L[l];
+        L.qkv = a.take<float>(RB * S * 3 * E);
+        L.P = a.take<float>(RB * nh * S * S);
+        L.ctx = a.take<float>(RB * S * E);
+        L.r1 = a.take<float>(RB * S * E);
+        L.x1 = a.take<float>(RB * S * E);
+        L.h = a.take<float>(RB * S * F);
+        L.r2 = a.take<float>(RB * S * E);
+        L.x2 = a.take<float>(RB * S * E);
+        L.st1 = a.take<float>(RB * S * 2);
+        L.st2 = a.take<float>(RB * S * 2);
+    }
+    c.t2i_q = a.take<float>(RB * E);
+    c.t2i_kv = a.take<float>(RB * S * 2 * E);
+    c.t2i_P = a.take<float>(RB * nh * S);
+    c.t2i_ctx = a.take<float>(RB * E);
+    c.t2i_out = a.take<float>(RB * E);
+    c.i2t_q = a.take<float>(RB * E);
+    c.i2t_kv = a.take<float>(RB * T * 2 * E);
+    c.i2t_P = a.take<float>(RB * nh * T);
+    c.i2t_ctx = a.take<float>(RB * E);
+    c.i2t_out = a.take<float>(RB * E);
+    c.c = a.take<float>(RB * E);
+}
+
+size_t carve(gg_engine* e, void* base) {
+    Arena a;
+    a.base = static_cast<char*>(base);
+    const long B = e->maxB, S = e->maxS, T = e->maxT, E = e->E, F = e->F, H = e->H, G = e->G, nh = e->nh;
+    const long R = e->maxR, RB = R * B, Rb = (R > 1 ? 2 : 1) * B;   // Rb: rows that take part in backward
+    const long P = e->maxP, Dp = e->Dp;
+    carve_cond(e, a, e->actsG, 1);
+    carve_cond(e, a, e->actsD, (int)R);
+    e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
+    e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
+    e->X2 = a.take<float>(2 * B * G);
+    e->c3 = a.take<float>(3 * B * E);
+    e->Pfr = a.take<float>(2 * B * H);
+    e->dseed = a.take<float>(2 * B);
+    e->dA = a.take<float>(3 * B * H);
+    e->dB = a.take<float>(3 * B * H);
+    e->dc = a.take<float>(3 * B * E);
+    e->gp_g2 = a.take<float>(B * H); e->gp_g1 = a.take<float>(B * H); e->gp_g1s = a.take<float>(B * H);
+    e->gp_grad = a.take<float>(B * G); e->gp_nrm2 = a.take<float>(B); e->gp_coef = a.take<float>(B);
+    e->gp_dg1 = a.take<float>(B * H); e->gp_dg2 = a.take<float>(B * H);
+    e->dxfake = a.take<float>(B * G);
+    e->sumsq = a.take<float>(4);
+    e->sPd = a.take<float>(RB * nh * S * S);
+    e->sdP = a.take<float>(Rb * nh * S * S);
+    e->sdqkv = a.take<float>(Rb * S * 3 * E);
+    e->sdx = a.take<float>(Rb * S * E);
+    e->sdr = a.take<float>(Rb * S * E);
+    e->sdres = a.take<float>(Rb * S * E);
+    e->sdctx = a.take<float>(Rb * S * E);
+    e->sdh = a.take<float>(Rb * S * F);
+    e->s_dt = a.take<float>(Rb * E); e->s_dp = a.take<float>(Rb * E); e->s_dq = a.take<float>(Rb * E);
+    e->s_tmpE = a.take<float>(Rb * E);
+    e->s_dkv = a.take<float>(Rb * S * 2 * E);
+    e->s_dkv2 = a.take<float>(Rb * T * 2 * E);
+    e->s_dtokrep = a.take<float>(Rb * T * E);
+    e->s_dtok = a.take<float>(B * T * E);
+    e->s_dx0 = a.take<float>(B * S * E);
+    e->s_demb = a.take<float>(B * P * E);
+    e->s_mod = a.take<float>(B * P * Dp);
+    e->s_dmod = a.take<float>(B * P * Dp);
+    e->s_dgb = a.take<float>(B * 2 * Dp);
+    return a.off + 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM helpers (Linear forward / backward-data / backward-weight)
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    gg_engine* e;
+    hipStream_t st;
+};
+
+inline long tiles_of(long M, long N) { return ((M + 127) / 128) * ((N + 127) / 128); }
+
+int run_gemm(Ctx& c, const GemmP& p) {
+    gg_engine* e = c.e;
+    e->launches++;
+    if (!e->prof_on) return gemm_f32(p, c.st);
+    if (e->prof_next + 2 > e->prof_pool.size()) {
+        for (int i = 0; i < 4096; ++i) {
+            hipEvent_t ev;
+            GG_CHECK_HIP(hipEventCreate(&ev));
+            e->prof_pool.push_back(ev);
+        }
+    }
+    gg_engine::ProfRec r;
+    r.cls = p.layA * 2 + p.layB;
+    const double b = (double)p.batch;
+    r.flops = 2.0 * p.M * p.N * (double)p.K * b;
+    r.bytes = 4.0 * b * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
+    r.e0 = e->prof_pool[e->prof_next++];
+    r.e1 = e->prof_pool[e->prof_next++];
+    GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
+    int rc = gemm_f32(p, c.st);
+    GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
+    e->prof_recs.push_back(r);
+    return rc;
+}
+
+// C[M,N] = act( A[M,K] @ W[N,K]^T + bias (+ C) )
+int lin_fwd(Ctx& c, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M,
+            int N, int K, int act = ACT_NONE, float slope = 0.f, int accumulate = 0) {
+    GemmP p;
+    p.A = A; p.B = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc;
+    p.layA = LAY_KC; p.layB = LAY_KC;
+    const long tiles = tiles_of(M, N);
+    if (tiles < 48 && K >= 1024 && ldc == N) {       // short-and-deep: split K over workgroups, finish elementwise
+        int sk = (int)std::min<long>((K + 255) / 256, std::max<long>(1, 256 / tiles));
+        if (!accumulate) { GG_TRY(k_fill(C, (long)M * N, 0.f, c.st)); c.e->launches++; }
+        p.splitk = sk;
+        GG_TRY(run_gemm(c, p));
+        if (bias || act != ACT_NONE) { GG_TRY(k_bias_act(C, bias, M, N, act, slope, c.st)); c.e->launches++; }
+        return 0;
+    }
+    p.bias = bias; p.act = act; p.slope = slope; p.accumulate = accumulate;
+    return run_gemm(c, p);
+}
+
+// dX[M,K] (+)= dY[M,N] @ W[N,K]
+int lin_bwd_data(Ctx& c, const float* dY, long ldy, const float* W, long ldw, float* dX, long ldx, int M, int N, int K,
+                 int accumulate = 0) {
+    GemmP p;
+    p.A = dY; p.B = W; p.C = dX; p.M = M; p.N = K; p.K = N; p.lda = ldy; p.ldb = ldw; p.ldc = ldx;
+    p.layA = LAY_KC; p.layB = LAY_KS;
+    const long tiles = tiles_of(M, K);
+    if (tiles < 48 && N >= 1024 && ldx == K) {
+        int sk = (int)std::min<long>((N + 255) / 256, std::max<long>(1, 256 / tiles));
+        if (!accumulate) { GG_TRY(k_fill(dX, (long)M * K, 0.f, c.st)); c.e->launches++; }
+        p.splitk = sk;
+        return run_gemm(c, p);
+    }
+    p.accumulate = accumulate;
+    return run_gemm(c, p);
+}
+
+// dW[N,K] += dY[M,N]^T @ X[M,K]     (reduction over the M rows, split over workgroups, fp32 atomics)
+int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K) {
+    GemmP p;
+    p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
+    p.layA = LAY_KS; p.layB = LAY_KS;
+    const long tiles = tiles_of(N, K);
+    long sk = std::max<long>(1, std::min<long>((M + 255) / 256, (512 + tiles - 1) / tiles));
+    p.splitk = (int)sk;
+    p.accumulate = 1;
+    return run_gemm(c, p);
+}
+
+#define KL(call)                 \
+    do {                         \
+        GG_TRY(call);            \
+        c.e->launches++;         \
+    } while (0)
+
+DropKey dkey(gg_engine* e, const CondActs& a, int net, int layer, int site) {
+    return make_drop_key(a.drop, e->seed, (uint32_t)(net * 1000 + layer * 10 + site), a.call);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conditioning stack forward (R:198-224)   [numpy_oracle.cond_fwd]
+// ------------------------------------------------------------------------------------------------
+int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float drop) {
+    gg_engine* e = c.e;
+    const int B = in->B, P = in->P, T = in->T, S = P + 1, E = e->E, F = e->F, nh = e->nh, dh = e->dh;
+    const int Dt = e->Dt, Dp = e->Dp;
+    const long RB = (long)R * B;
+    a.B = B; a.R = R; a.P = P; a.T = T; a.drop = drop; a.call = ++e->call_counter;
+    const float* w = n.w;
+    // FiLM parameters from the text CLS token (row b of `text` viewed with ld = T*Dt)
+    GG_TRY(lin_fwd(c, in->text, (long)T * Dt, w + n.film_w, Dt, w + n.film_b, a.gbpre, 2 * Dp, B, 2 * Dp, Dt));
+    KL(k_film_act_fwd(a.gbpre, a.gb, B, Dp, c.st));
+    // text encoder
+    GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt));
+    // patch encoder with FiLM fused on the A operand; rows land behind the CLS row of each sample
+    {
+        GemmP p;
+        p.A = in->patches; p.B = w + n.pe_w; p.C = a.x0; p.M = B * P; p.N = E; p.K = Dp;
+        p.lda = Dp; p.ldb = Dp; p.ldc = E; p.bias = w + n.pe_b;
+        p.film_gamma = a.gb; p.film_beta = a.gb + Dp; p.film_ld = 2 * Dp; p.film_group = P; p.c_row_group = P;
+        GG_TRY(run_gemm(c, p));
+    }
+    KL(k_write_cls(a.x0, w + n.cls, B, S, E, c.st));
+    KL(k_build_mask(in->patch_pad, a.mask, B, P, c.st));
+    const float* x_in = a.x0;
+    const float* tok = a.tok;
+    if (R > 1) {
+        KL(k_copy_rows_bcast(a.xrep, a.x0, RB * S, (long)B * S, E, c.st));
+        KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
+        x_in = a.xrep;
+        tok = a.tokrep;
+    }
+    const float scale = 1.f / sqrtf((float)dh);
+    for (int l = 0; l < e->nl; ++l) {
+        LayerActs& L = a.L[l];
+        const LayerP& lp = n.layer[l];
+        GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E));
+        {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
+            GemmP p;
+            p.A = L.qkv; p.B = L.qkv + E; p.C = L.P; p.M = S; p.N = S; p.K = dh;
+            p.lda = 3 * E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
+            p.batch = (int)(RB * nh); p.batch_inner = nh;
+            p.sAo = (long)S * 3 * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh;
+            p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
+            p.alpha = scale; p.colmask = a.mask; p.colmask_stride = S; p.colmask_mod = B;
+            GG_TRY(run_gemm(c, p));
+        }
+        const DropKey kA = dkey(e, a, n.role, l, 0);
+        KL(k_softmax_rows(L.P, e->sPd, RB * nh * S, S, kA, c.st));
+        {   // ctx[b,:,h] = Pd[b,h] V_h
+            GemmP p;
+            p.A = drop > 0.f ? e->sPd : L.P; p.B = L.qkv + 2 * E; p.C = L.ctx; p.M = S; p.N = dh; p.K = S;
+            p.lda = S; p.ldb = 3 * E; p.ldc = E; p.layA = LAY_KC; p.layB = LAY_KS;
+            p.batch = (int)(RB * nh); p.batch_inner = nh;
+            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh;
+            p.sCo = (long)S * E; p.sCi = dh;
+            GG_TRY(run_gemm(c, p));
+        }
+        GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
+        KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
+        GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
+        if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
+        GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
+        KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
+        x_in = L.x2;
+    }
+    // T2I: query = text CLS embedding, keys = values = encoder output (R:218)
+    GG_TRY(lin_fwd(c, tok, (long)T * E, w + n.t2i.inw, E, w + n.t2i.inb, a.t2i_q, E, (int)RB, E, E));
+    GG_TRY(lin_fwd(c, x_in, E, w + n.t2i.inw + (long)E * E, E, w + n.t2i.inb + E, a.t2i_kv, 2 * E, (int)(RB * S), 2 * E, E));
+    KL(k_sq_attn_fwd(a.t2i_q, a.t2i_kv, a.mask, B, a.t2i_P, a.t2i_ctx, (int)RB, S, E, nh, c.st));
+    GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
+    // I2T: query = that vector, keys = values = encoded text tokens (R:220)
+    GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
+    GG_TRY(lin_fwd(c, tok, E, w + n.i2t.inw + (long)E * E, E, w + n.i2t.inb + E, a.i2t_kv, 2 * E, (int)(RB * T), 2 * E, E));
+    KL(k_sq_attn_fwd(a.i2t_q, a.i2t_kv, in->text_pad, B, a.i2t_P, a.i2t_ctx, (int)RB, T, E, nh, c.st));
+    GG_TRY(lin_fwd(c, a.i2t_ctx, E, w + n.i2t.ow, E, w + n.i2t.ob, a.i2t_out, E, (int)RB, E, E));
+    KL(k_copy(a.c, a.t2i_out, RB * E, c.st));
+    KL(k_axpy(a.c, a.i2t_out, 1.f, RB * E, c.st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conditioning stack backward   [numpy_oracle.cond_bwd]
+// dc: [Rb*B, E] gradient w.r.t. the conditioning vector of the first Rb replicas
+// ------------------------------------------------------------------------------------------------
+int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* dc, int Rb) {
+    gg_engine* e = c.e;
+    const int B = a.B, P = a.P, T = a.T, S = P + 1, E = e->E, F = e->F, nh = e->nh, dh = e->dh;
+    const int Dt = e->Dt, Dp = e->Dp;
+    const long RB = (long)Rb * B;
+    const float* w = n.w;
+    float* g = n.g;
+    const float* tok = a.R > 1 ? a.tokrep : a.tok;
+    const float* enc = a.L[e->nl - 1].x2;
+    const float drop = a.drop;
+    const float ks = drop > 0.f ? 1.f / (1.f - drop) : 1.f;
+
+    // ---- I2T backward: t = out_proj(ctx); scores over text tokens; q from p -----------------------
+    GG_TRY(lin_bwd_weight(c, dc, E, a.i2t_ctx, E, g + n.i2t.ow, E, (int)RB, E, E));
+    KL(k_colsum(dc, RB, E, E, g + n.i2t.ob, c.st));
+    GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_tmpE, E, (int)RB, E, E));
+    KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
+    GG_TRY(lin_bwd_weight(c, e->s_dq, E, a.t2i_out, E, g + n.i2t.inw, E, (int)RB, E, E));
+    KL(k_colsum(e->s_dq, RB, E, E, g + n.i2t.inb, c.st));
+    KL(k_copy(e->s_dp, dc, RB * E, c.st));                                        // c = t + p
+    GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.i2t.inw, E, e->s_dp, E, (int)RB, E, E, 1));
+    GG_TRY(lin_bwd_weight(c, e->s_dkv2, 2 * E, tok, E, g + n.i2t.inw + (long)E * E, E, (int)(RB * T), 2 * E, E));
+    KL(k_colsum(e->s_dkv2, RB * T, 2 * E, 2 * E, g + n.i2t.inb + E, c.st));
+    GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
+    // ---- T2I backward ---------------------------------------------------------------------------------
+    GG_TRY(lin_bwd_weight(c, e->s_dp, E, a.t2i_ctx, E, g + n.t2i.ow, E, (int)RB, E, E));
+    KL(k_colsum(e->s_dp, RB, E, E, g + n.t2i.ob, c.st));
+    GG_TRY(lin_bwd_data(c, e->s_dp, E, w + n.t2i.ow, E, e->s_tmpE, E, (int)RB, E, E));
+    KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
+    GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+    KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
+    GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+    GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
+    KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
+    GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E));
+    // ---- encoder layers, last to first ---------------------------------------------------------------
+    float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
+    for (int l = e->nl - 1; l >= 0; --l) {
+        LayerActs& L = a.L[l];
+        const LayerP& lp = n.layer[l];
+        const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 ? a.xrep : a.x0);
+        // LN2
+        KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, RB * S, E,
+                           dkey(e, a, n.role, l, 3), c.st));
+        // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))
+        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F));
+        KL(k_colsum(e->sdres, RB * S, E, E, g + lp.l2b, c.st));
+        GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.l2w, F, e->sdh, F, (int)(RB * S), E, F));
+        KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));      // (h>0) covers ReLU and the kept-mask
+        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E));
+        KL(k_colsum(e->sdh, RB * S, F, F, g + lp.l1b, c.st));
+        GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1));   // dx1 = dr2 + ...
+        // LN1
+        KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, RB * S, E,
+                           dkey(e, a, n.role, l, 1), c.st));
+        // self attention out-proj
+        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E));
+        KL(k_colsum(e->sdres, RB * S, E, E, g + lp.sa.ob, c.st));
+        GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E));
+        const DropKey kA = dkey(e, a, n.role, l, 0);
+        const float* Pd = L.P;
+        if (drop > 0.f) {
+            KL(k_dropout_copy(e->sPd, L.P, RB * nh * S * S, kA, c.st));
+            Pd = e->sPd;
+        }
+        GemmP p;
+        const int nb = (int)(RB * nh);
+        {   // dPd = dctx_h V_h^T
+            p = GemmP();
+            p.A = e->sdctx; p.B = L.qkv + 2 * E; p.C = e->sdP; p.M = S; p.N = S; p.K = dh;
+            p.lda = E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
+            p.batch = nb; p.batch_inner = nh;
+            p.sAo = (long)S * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
+            GG_TRY(run_gemm(c, p));
+        }
+        {   // dV_h = Pd^T dctx_h
+            p = GemmP();
+            p.A = Pd; p.B = e->sdctx; p.C = e->sdqkv + 2 * E; p.M = S; p.N = dh; p.K = S;
+            p.lda = S; p.ldb = E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
+            p.batch = nb; p.batch_inner = nh;
+            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+            GG_TRY(run_gemm(c, p));
+        }
+        KL(k_softmax_bwd_rows(e->sdP, L.P, (long)nb * S, S, 1.f / sqrtf((float)dh), kA, c.st));
+        {   // dQ_h = dS K_h
+            p = GemmP();
+            p.A = e->sdP; p.B = L.qkv + E; p.C = e->sdqkv; p.M = S; p.N = dh; p.K = S;
+            p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KC; p.layB = LAY_KS;
+            p.batch = nb; p.batch_inner = nh;
+            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+            GG_TRY(run_gemm(c, p));
+        }
+        {   // dK_h = dS^T Q_h
+            p = GemmP();
+            p.A = e->sdP; p.B = L.qkv; p.C = e->sdqkv + E; p.M = S; p.N = dh; p.K = S;
+            p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
+            p.batch = nb; p.batch_inner = nh;
+            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+            GG_TRY(run_gemm(c, p));
+        }
+        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E));
+        KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st));
+        GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1));   // dx_in = dr1 + ...
+    }
+    // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
+    const float* dx0 = dx;
+    const float* dtok = e->s_dtokrep;
+    if (Rb > 1) {
+        KL(k_fold(e->s_dx0, dx, (long)B * S * E, Rb, c.st));
+        KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
+        dx0 = e->s_dx0;
+        dtok = e->s_dtok;
+    }
+    KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
+    KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
+    KL(k_film_mod(in->patches, a.gb, e->s_mod, B, P, Dp, c.st));
+    GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
+    KL(k_colsum(e->s_demb, (long)B * P, E, E, g + n.pe_b, c.st));
+    GG_TRY(lin_bwd_data(c, e->s_demb, E, w + n.pe_w, Dp, e->s_dmod, Dp, B * P, E, Dp));
+    KL(k_film_bwd_reduce(e->s_dmod, in->patches, e->s_dgb, B, P, Dp, c.st));
+    KL(k_film_act_bwd(e->s_dgb, a.gb, a.gbpre, B, Dp, c.st));
+    GG_TRY(lin_bwd_weight(c, e->s_dgb, 2 * Dp, in->text, (long)T * Dt, g + n.film_w, Dt, B, 2 * Dp, Dt));
+    KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));
+    GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
+    KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP heads (R:226-231)
+// ------------------------------------------------------------------------------------------------
+// a1 (+)= cvec @ W1c^T + b1, act ; a2 = act(a1 W2^T + b2) ; out = a2 W3^T + b3
+// `a1` must already hold v @ W1v^T (the non-conditioning part of the first layer).
+int head_finish(Ctx& c, Net& n, const float* cvec, float* a1, float* a2, float* out, long ldo, int rows, int out_rows) {
+    gg_engine* e = c.e;
+    const int E = e->E, H = e->H;
+    const float* w = n.w;
+    const float slope = e->cfg.negative_slope;
+    GG_TRY(lin_fwd(c, cvec, E, w + n.w1 + n.V, n.V + E, w + n.b1, a1, H, rows, H, E, ACT_LRELU, slope, 1));
+    GG_TRY(lin_fwd(c, a1, H, w + n.w2, H, w + n.b2, a2, H, rows, H, H, ACT_LRELU, slope));
+    if (out && out_rows > 0) GG_TRY(lin_fwd(c, a2, H, w + n.w3, H, w + n.b3, out, ldo, out_rows, n.OUT, H));
+    return 0;
+}
+
+// backward through one head for `rows` rows.  dout [rows, OUT].  vin: the non-conditioning input
+// [rows, V], cvec [rows, E].  If param_grads: accumulate the six parameter gradients.  Outputs:
+// dcond [rows,E] (may be null), dv [rows,V] (may be null).
+int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const float* cvec, const float* a1, const float* a2,
+                  int rows, bool param_grads, float* dcond, float* dv) {
+    gg_engine* e = c.e;
+    const int E = e->E, H = e->H, V = n.V, OUT = n.OUT;
+    const float* w = n.w;
+    float* g = n.g;
+    const float slope = e->cfg.negative_slope;
+    float* dh2 = e->dA;
+    float* dh1 = e->dB;
+    if (param_grads) {
+        GG_TRY(lin_bwd_weight(c, dout, OUT, a2, H, g + n.w3, H, rows, OUT, H));
+        KL(k_colsum(dout, rows, OUT, OUT, g + n.b3, c.st));
+    }
+    GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));
+    KL(k_act_bwd(dh2, a2, (long)rows * H, slope, 1.f, c.st));
+    if (param_grads) {
+        GG_TRY(lin_bwd_weight(c, dh2, H, a1, H, g + n.w2, H, rows, H, H));
+        KL(k_colsum(dh2, rows, H, H, g + n.b2, c.st));
+    }
+    GG_TRY(lin_bwd_data(c, dh2, H, w + n.w2, H, dh1, H, rows, H, H));
+    KL(k_act_bwd(dh1, a1, (long)rows * H, slope, 1.f, c.st));
+    if (param_grads) {
+        GG_TRY(lin_bwd_weight(c, dh1, H, vin, V, g + n.w1, V + E, rows, H, V));
+        GG_TRY(lin_bwd_weight(c, dh1, H, cvec, E, g + n.w1 + V, V + E, rows, H, E));
+        KL(k_colsum(dh1, rows, H, H, g + n.b1, c.st));
+    }
+    if (dcond) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1 + V, V + E, dcond, E, rows, H, E));
+    if (dv) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1, V + E, dv, V, rows, H, V));
+    return 0;
+}
+
+int generator_forward(Ctx& c, const float* z, const gg_cond* in, float* x_out, int train) {
+    gg_engine* e = c.e;
+    Net& n = e->net[GG_ROLE_GENERATOR];
+    const int B = in->B;
+    GG_TRY(cond_forward(c, n, in, e->actsG, 1, train ? e->dropout : 0.f));
+    GG_TRY(lin_fwd(c, z, e->L, n.w + n.w1, e->L + e->E, nullptr, e->headG.a1, e->H, B, e->H, e->L));
+    GG_TRY(head_finish(c, n, e->actsG.c, e->headG.a1, e->headG.a2, x_out, e->G, B, B));
+    return 0;
+}
+
+int check_cond(gg_engine* e, const gg_cond* c) {
+    GG_REQUIRE(c && c->patches && c->patch_pad && c->text && c->text_pad, "null conditioning input");
+    GG_REQUIRE(c->B >= 1 && c->B <= e->maxB, "batch exceeds max_batch");
+    GG_REQUIRE(c->P >= 1 && c->P <= e->maxP, "patch count exceeds max_patches");
+    GG_REQUIRE(c->T >= 1 && c->T <= e->maxT, "text token count exceeds max_text_tokens");
+    GG_REQUIRE(e->ws != nullptr, "workspace not bound");
+    GG_REQUIRE(e->net[0].w && e->net[1].w, "parameters not bound");
+    return 0;
+}
+
+int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
+    gg_engine* e = c.e;
+    GG_REQUIRE(n.w && n.g && n.s1, "network buffers not bound");
+    GG_REQUIRE(e->cfg.optimizer == GG_OPT_RMSPROP || n.s2, "Adam needs the second state buffer");
+    float* ss = e->sumsq + n.role;
+    KL(k_fill(ss, 1, 0.f, c.st));
+    if (max_norm > 0.f) KL(k_sumsq(n.g, n.total, ss, c.st));
+    n.step_t += 1;
+    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.total, e->cfg.optimizer, n.lr, max_norm, ss, grad_scale, n.step_t, c.st));
+    return 0;
+}
+
+int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses) {
+    gg_engine* e = c.e;
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int B = in->B, G = e->G, E = e->E, H = e->H;
+    const float slope = e->cfg.negative_slope;
+    const int R = e->dropout > 0.f ? 3 : 1;
+    GG_REQUIRE(R <= e->maxR, "workspace was sized for dropout == 0; recreate the engine with dropout > 0");
+    KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
+    KL(k_fill(D.g, D.total, 0.f, c.st));
+    // x_fake = G(z) (generator frozen: no activations kept beyond this call)   R:391
+    GG_TRY(generator_forward(c, z, in, e->X2, 1));
+    KL(k_copy(e->X2 + (long)B * G, x_real, (long)B * G, c.st));
+    // critic conditioning: R independent dropout replicas (fake, real, interpolate) R:403,404,360
+    GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout));
+    if (R == 1) KL(k_copy_rows_bcast(e->c3, e->actsD.c, 3L * B, B, E, c.st));
+    else KL(k_copy(e->c3, e->actsD.c, 3L * B * E, c.st));
+    // first layer, gene part, for fake and real rows at once; the interpolate's is their lerp
+    GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->Pfr, H, 2 * B, H, G));
+    KL(k_copy(e->headD.a1, e->Pfr, 2L * B * H, c.st));
+    KL(k_lerp_rows(e->Pfr, alpha, e->headD.a1 + 2L * B * H, B, H, c.st));
+    GG_TRY(head_finish(c, D, e->c3, e->headD.a1, e->headD.a2, e->headD.out, 1, 3 * B, 2 * B));
+    KL(k_critic_loss_seed(e->headD.out, e->dseed, losses, B, c.st));
+    // D_loss backward through the head for the 2B fake/real rows
+    GG_TRY(head_backward(c, D, e->dseed, e->X2, e->c3, e->headD.a1, e->headD.a2, 2 * B, true, e->dc, nullptr));
+    // ---- gradient penalty, closed form on the interpolate rows -------------------------
+    const float* a1h = e->headD.a1 + 2L * B * H;
+    const float* a2h = e->headD.a2 + 2L * B * H;
+    KL(k_mask_times_vec(e->gp_g2, a2h, D.w + D.w3, B, H, slope, c.st));                    // g2 = m2 * w3
+    GG_TRY(lin_bwd_data(c, e->gp_g2, H, D.w + D.w2, H, e->gp_g1, H, B, H, H));           // u = g2 W2
+    KL(k_act_bwd(e->gp_g1, a1h, (long)B * H, slope, 1.f, c.st));                           // g1 = m1 * u
+    GG_TRY(lin_bwd_data(c, e->gp_g1, H, D.w + D.w1, G + E, e->gp_grad, G, B, H, G));     // grad = g1 W1x
+    KL(k_row_sumsq(e->gp_grad, e->gp_nrm2, B, G, c.st));
+    KL(k_gp_coef(e->gp_nrm2, e->gp_coef, losses, B, e->cfg.gp_weight, c.st));
+    KL(k_copy(e->gp_g1s, e->gp_g1, (long)B * H, c.st));
+    KL(k_rowscale(e->gp_g1s, e->gp_coef, B, H, c.st));
+    GG_TRY(lin_bwd_weight(c, e->gp_g1s, H, e->gp_grad, G, D.g + D.w1, G + E, B, H, G));    // dW1x += (coef g1)^T grad
+    GG_TRY(lin_fwd(c, e->gp_grad, G, D.w + D.w1, G + E, nullptr, e->gp_dg1, H, B, H, G)); // grad W1x^T
+    KL(k_rowscale(e->gp_dg1, e->gp_coef, B, H, c.st));                                     // dg1 = s W1x^T
+    KL(k_act_bwd(e->gp_dg1, a1h, (long)B * H, slope, 1.f, c.st));                          // du = m1 * dg1
+    GG_TRY(lin_bwd_weight(c, e->gp_g2, H, e->gp_dg1, H, D.g + D.w2, H, B, H, H));         // dW2 += g2^T du
+    GG_TRY(lin_fwd(c, e->gp_dg1, H, D.w + D.w2, H, nullptr, e->gp_dg2, H, B, H, H));     // dg2 = du W2^T
+    KL(k_colsum_masked(e->gp_dg2, a2h, B, H, slope, D.g + D.w3, c.st));                    // dw3 += sum m2*dg2
+    // ---- conditioning backward for the rows that carry gradient --------------------------------------
+    if (R == 1) {
+        KL(k_axpy(e->dc, e->dc + (long)B * E, 1.f, (long)B * E, c.st));
+        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 1));
+    } else {
+        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 2));
+    }
+    return 0;
+}
+
+int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
+    gg_engine* e = c.e;
+    Net& Gn = e->net[GG_ROLE_GENERATOR];
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int B = in->B, G = e->G, E = e->E, H = e->H, L = e->L;
+    KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
+    KL(k_fill(Gn.g, Gn.total, 0.f, c.st));
+    GG_TRY(generator_forward(c, z, in, e->X2, 1));                       // R:441 (activations kept in actsG/headG)
+    GG_TRY(cond_forward(c, D, in, e->actsD, 1, e->dropout));             // R:449
+    GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->headD.a1, H, B, H, G));
+    GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, e->headD.out, 1, B, B));
+    KL(k_gen_loss_seed(e->headD.out, e->dseed, losses, B, c.st));
+    // through the frozen critic head down to x_fake, then the generator head and conditioning stack
+    GG_TRY(head_backward(c, D, e->dseed, nullptr, nullptr, e->headD.a1, e->headD.a2, B, false, nullptr, e->dxfake));
+    GG_TRY(head_backward(c, Gn, e->dxfake, z, e->actsG.c, e->headG.a1, e->headG.a2, B, true, e->dc, nullptr));
+    (void)L;
+    GG_TRY(cond_backward(c, Gn, in, e->actsG, e->dc, 1));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* gg_last_error(void) { return gg::g_err.c_str(); }
+const char* gg_version(void) { return "gemm_gan_amd 0.1 (gfx950, f32-MFMA parity path)"; }
+
+int gg_create(const gg_config* cfg, gg_engine** out) {
+    GG_REQUIRE(cfg && out, "null argument");
+    GG_REQUIRE(cfg->n_heads > 0 && cfg->embedding_dims % cfg->n_heads == 0, "embedding_dims must divide by n_heads");
+    GG_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= MAXL, "n_layers out of range");
+    GG_REQUIRE(cfg->embedding_dims <= 1024, "embedding_dims > 1024 unsupported");
+    GG_REQUIRE(cfg->max_patches + 1 <= 2048 && cfg->max_text_tokens <= 2048, "sequence too long");
+    GG_REQUIRE(cfg->n_genes > 0 && cfg->latent_dims > 0 && cfg->hidden_dims > 0 && cfg->text_dims > 0 && cfg->patch_dims > 0, "bad dims");
+    GG_REQUIRE(cfg->max_batch > 0 && cfg->max_patches > 0 && cfg->max_text_tokens > 0, "bad capacity");
+    GG_REQUIRE(cfg->dropout >= 0.f && cfg->dropout < 1.f, "bad dropout");
+    gg_engine* e = new gg_engine();
+    e->cfg = *cfg;
+    e->E = cfg->embedding_dims; e->F = 2 * e->E; e->H = cfg->hidden_dims; e->G = cfg->n_genes; e->L = cfg->latent_dims;
+    e->Dt = cfg->text_dims; e->Dp = cfg->patch_dims; e->nh = cfg->n_heads; e->nl = cfg->n_layers; e->dh = e->E / e->nh;
+    e->maxB = cfg->max_batch; e->maxP = cfg->max_patches; e->maxT = cfg->max_text_tokens; e->maxS = e->maxP + 1;
+    e->maxR = cfg->dropout > 0.f ? 3 : 1;
+    e->dropout = cfg->dropout;
+    e->seed = cfg->seed;
+    build_net(e, GG_ROLE_GENERATOR);
+    build_net(e, GG_ROLE_CRITIC);
+    e->net[GG_ROLE_GENERATOR].lr = cfg->lr_g;
+    e->net[GG_ROLE_CRITIC].lr = cfg->lr_d;
+    e->ws_bytes = carve(e, nullptr);
+    *out = e;
+    return 0;
+}
+
+void gg_destroy(gg_engine* e) { delete e; }
+
+int gg_param_count(const gg_engine* e, int role) { return e && (role == 0 || role == 1) ? (int)e->net[role].ps.size() : -1; }
+const char* gg_param_name(const gg_engine* e, int role, int i) {
+    if (!e || role < 0 || role > 1 || i < 0 || i >= (int)e->net[role].ps.size()) return nullptr;
+    return e->net[role].ps[i].name.c_str();
+}
+int gg_param_info(const gg_engine* e, int role, int i, int64_t* offset, int64_t* numel, int32_t* ndim, int32_t shape[3]) {
+    GG_REQUIRE(e && (role == 0 || role == 1) && i >= 0 && i < (int)e->net[role].ps.size(), "bad parameter index");
+    const ParamInfo& p = e->net[role].ps[i];
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (ndim) *ndim = p.ndim;
+    if (shape) { shape[0] = p.shape[0]; shape[1] = p.shape[1]; shape[2] = p.shape[2]; }
+    return 0;
+}
+int64_t gg_flat_numel(const gg_engine* e, int role) { return e && (role == 0 || role == 1) ? e->net[role].total : -1; }
+
+int gg_bind_net(gg_engine* e, int role, float* params, float* grads, float* s1, float* s2) {
+    GG_REQUIRE(e && (role == 0 || role == 1), "bad role");
+    GG_REQUIRE(params && grads, "null buffer");
+    GG_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0), "buffers must be 16-byte aligned");
+    Net& n = e->net[role];
+    n.w = params; n.g = grads; n.s1 = s1; n.s2 = s2;
+    return 0;
+}
+size_t gg_workspace_bytes(const gg_engine* e) { return e ? e->ws_bytes : 0; }
+int gg_bind_workspace(gg_engine* e, void* ws, size_t bytes) {
+    GG_REQUIRE(e && ws, "null argument");
+    GG_REQUIRE(bytes >= e->ws_bytes, "workspace too small");
+    GG_REQUIRE((uintptr_t)ws % 256 == 0, "workspace must be 256-byte aligned");
+    e->ws = ws;
+    carve(e, ws);
+    return 0;
+}
+
+int gg_forward(gg_engine* e, int role, const float* v, const gg_cond* in, float* out, int train, void* stream) {
+    GG_REQUIRE(e && v && out, "null argument");
+    GG_REQUIRE(role == 0 || role == 1, "bad role");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    if (role == GG_ROLE_GENERATOR) return generator_forward(c, v, in, out, train);
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int B = in->B;
+    GG_TRY(cond_forward(c, D, in, e->actsD, 1, train ? e->dropout : 0.f));
+    GG_TRY(lin_fwd(c, v, e->G, D.w + D.w1, e->G + e->E, nullptr, e->headD.a1, e->H, B, e->H, e->G));
+    GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, out, 1, B, B));
+    return 0;
+}
+
+int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const float* alpha, const gg_cond* in,
+                       float* losses, void* stream) {
+    GG_REQUIRE(e && x_real && z && alpha && losses, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return critic_backward(c, x_real, z, alpha, in, losses);
+}
+int gg_critic_apply(gg_engine* e, float grad_scale, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    Ctx c{e, (hipStream_t)stream};
+    return apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, grad_scale);
+}
+int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* in, float* losses, void* stream) {
+    GG_REQUIRE(e && z && losses, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return generator_backward(c, z, in, losses);
+}
+int gg_generator_apply(gg_engine* e, float grad_scale, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    Ctx c{e, (hipStream_t)stream};
+    return apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, grad_scale);
+}
+
+int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const float* z_all, const float* alpha_all,
+                  int n_critic, float* losses, void* stream) {
+    GG_REQUIRE(e && x_real && z_all && alpha_all && losses, "null argument");
+    GG_REQUIRE(n_critic >= 0, "bad n_critic");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    e->launches = 0;
+    const long zs = (long)in->B * e->L;
+    for (int k = 0; k < n_critic; ++k) {
+        GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses));
+        GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
+    }
+    GG_TRY(generator_backward(c, z_all + n_critic * zs, in, losses));
+    GG_TRY(apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, 1.f));
+    return 0;
+}
+
+int gg_set_lr(gg_engine* e, int role, float lr) {
+    GG_REQUIRE(e && (role == 0 || role == 1), "bad role");
+    e->net[role].lr = lr;
+    return 0;
+}
+int gg_set_dropout(gg_engine* e, float p) {
+    GG_REQUIRE(e && p >= 0.f && p < 1.f, "bad dropout");
+    GG_REQUIRE(!(p > 0.f && e->maxR < 3), "engine was created with dropout == 0 (workspace sized for one replica)");
+    e->dropout = p;
+    return 0;
+}
+int gg_set_seed(gg_engine* e, uint64_t seed) {
+    GG_REQUIRE(e, "null argument");
+    e->seed = seed;
+    e->call_counter = 0;
+    return 0;
+}
+int gg_reset_optimizer_steps(gg_engine* e) {
+    GG_REQUIRE(e, "null argument");
+    e->net[0].step_t = e->net[1].step_t = 0;
+    return 0;
+}
+int gg_get_optimizer_step(const gg_engine* e, int role) { return e && (role == 0 || role == 1) ? e->net[role].step_t : -1; }
+int gg_set_optimizer_step(gg_engine* e, int role, int step) {
+    GG_REQUIRE(e && (role == 0 || role == 1) && step >= 0, "bad argument");
+    e->net[role].step_t = step;
+    return 0;
+}
+int64_t gg_launch_count(const gg_engine* e) { return e ? e->launches : -1; }
+
+int gg_profile_enable(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->prof_on = on != 0;
+    if (on) { e->prof_recs.clear(); e->prof_next = 0; }
+    return 0;
+}
+int gg_profile_collect(gg_engine* e) {
+    if (!e) return -1;
+    static const char* names[4] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>"};
+    e->prof_agg.assign(4, gg_engine::ProfAgg());
+    for (int i = 0; i < 4; ++i) e->prof_agg[i].name = names[i];
+    for (auto& r : e->prof_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("hipEventSynchronize failed"); return -1; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { set_error("hipEventElapsedTime failed"); return -1; }
+        auto& a = e->prof_agg[r.cls];
+        a.launches++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    e->prof_recs.clear();
+    e->prof_next = 0;
+    return (int)e->prof_agg.size();
+}
+int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes) {
+    GG_REQUIRE(e && index >= 0 && index < (int)e->prof_agg.size(), "bad index");
+    const auto& a = e->prof_agg[index];
+    if (name && name_cap > 0) { strncpy(name, a.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = a.launches;
+    if (ms) *ms = a.ms;
+    if (flops) *flops = a.flops;
+    if (bytes) *bytes = a.bytes;
+    return 0;
+}
+
+int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel) {
+    GG_REQUIRE(e && name && ptr && numel, "null argument");
+    GG_REQUIRE(e->ws, "workspace not bound");
+    std::string s(name);
+    auto ret = [&](void* p, long n) { *ptr = p; *numel = n; return 0; };
+    const long E = e->E, F = e->F, H = e->H, G = e->G, nh = e->nh, Dp = e->Dp;
+    if (s.size() > 2 && s[1] == '.' && (s[0] == 'G' || s[0] == 'D')) {
+        CondActs& a = s[0] == 'G' ? e->actsG : e->actsD;
+        const long B = a.B, RB = (long)a.R * a.B, S = a.P + 1, T = a.T;
+        std::string f = s.substr(2);
+        if (f == "gbpre") return ret(a.gbpre, B * 2 * Dp);
+        if (f == "gb") return ret(a.gb, B * 2 * Dp);
+        if (f == "tok") return ret(a.tok, B * T * E);
+        if (f == "x0") return ret(a.x0, B * S * E);
+        if (f == "c") return ret(a.c, RB * E);
+        if (f == "t2i_out") return ret(a.t2i_out, RB * E);
+        if (f == "i2t_out") return ret(a.i2t_out, RB * E);
+        if (f == "t2i_P") return ret(a.t2i_P, RB * nh * S);
+        if (f == "i2t_P") return ret(a.i2t_P, RB * nh * T);
+        if (f == "t2i_kv") return ret(a.t2i_kv, RB * S * 2 * E);
+        if (f.size() > 3 && f[0] == 'L' && f[2] == '.') {
+            const int l = f[1] - '0';
+            GG_REQUIRE(l >= 0 && l < e->nl, "bad layer index");
+            LayerActs& L = a.L[l];
+            std::string k = f.substr(3);
+            if (k == "qkv") return ret(L.qkv, RB * S * 3 * E);
+            if (k == "P") return ret(L.P, RB * nh * S * S);
+            if (k == "ctx") return ret(L.ctx, RB * S * E);
+            if (k == "r1") return ret(L.r1, RB * S * E);
+            if (k == "x1") return ret(L.x1, RB * S * E);
+            if (k == "h") return ret(L.h, RB * S * F);
+            if (k == "x2") return ret(L.x2, RB * S * E);
+        }
+    } else {
+        const long B = e->actsD.B ? e->actsD.B : e->actsG.B;
+        if (s == "X2") return ret(e->X2, 2 * B * G);
+        if (s == "Pfr") return ret(e->Pfr, 2 * B * H);
+        if (s == "headD.a1") return ret(e->headD.a1, 3 * B * H);
+        if (s == "headD.a2") return ret(e->headD.a2, 3 * B * H);
+        if (s == "headD.out") return ret(e->headD.out, 2 * B);
+        if (s == "headG.a1") return ret(e->headG.a1, B * H);
+        if (s == "gp_grad") return ret(e->gp_grad, B * G);
+        if (s == "gp_nrm2") return ret(e->gp_nrm2, B);
+        if (s == "gp_coef") return ret(e->gp_coef, B);
+        if (s == "dc") return ret(e->dc, 2 * B * E);
+        if (s == "dxfake") return ret(e->dxfake, B * G);
+        if (s == "sPd") return ret(e->sPd, (long)e->actsD.R * B * nh * (e->actsD.P + 1) * (e->actsD.P + 1));
+    }
+    set_error("unknown debug buffer '" + s + "'");
+    return -3;
+}
+
+int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                 int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                 void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_f32(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Row-wise / elementwise HIP kernels of the engine (host launch wrappers).  All pointers are
+// device pointers, all tensors fp32 row-major contiguous unless a leading dimension is given.
+#pragma once
+#include "gg_common.h"
+
+namespace gg {
+
+// counter-hash dropout stream: element i of site `site` in forward call `call` (see kernels.hip)
+struct DropKey {
+    float p = 0.f;          // drop probability; 0 => disabled
+    uint32_t k0 = 0, k1 = 0;
+};
+DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call);
+
+int k_fill(float* x, long n, float v, hipStream_t st);
+int k_copy(float* dst, const float* src, long n, hipStream_t st);
+// dst[r, :] = src[r % src_rows, :]   (replica broadcast)
+int k_copy_rows_bcast(float* dst, const float* src, long rows, long src_rows, int cols, hipStream_t st);
+int k_axpy(float* y, const float* x, float a, long n, hipStream_t st);          // y += a*x
+int k_add_bcast_rows(float* y, const float* x, long rows, long x_rows, int cols, hipStream_t st);  // y[r]+=x[r%x_rows]
+
+// FiLM head: gb_pre [B, 2*Dp] -> gb (gamma = tanh(first half), beta = clamp(second half, -5, 5))
+int k_film_act_fwd(const float* gb_pre, float* gb, int B, int Dp, hipStream_t st);
+// d(gb_pre) from d(gamma|beta) (in dgb, overwritten), needs gb (post) and gb_pre
+int k_film_act_bwd(float* dgb, const float* gb, const float* gb_pre, int B, int Dp, hipStream_t st);
+// mod[b,p,:] = gamma[b,:]*patches[b,p,:] + beta[b,:]
+int k_film_mod(const float* patches, const float* gb, float* mod, int B, int P, int Dp, hipStream_t st);
+// dgb[b, 0:Dp] = sum_p dmod*patches ; dgb[b, Dp:2Dp] = sum_p dmod
+int k_film_bwd_reduce(const float* dmod, const float* patches, float* dgb, int B, int P, int Dp, hipStream_t st);
+
+// seq[b,0,:] = cls[:]  for b in [0,B)
+int k_write_cls(float* seq, const float* cls, int B, int S, int E, hipStream_t st);
+// dcls[:] += sum_b dseq[b,0,:]
+int k_cls_grad(const float* dseq, float* dcls, int B, int S, int E, hipStream_t st);
+// mask_out[b,0]=0 ; mask_out[b,1+p] = pad[b,p]   (bytes)
+int k_build_mask(const uint8_t* pad, uint8_t* mask_out, int B, int P, hipStream_t st);
+
+// in-place masked softmax over rows of length cols (masked entries already hold -inf).  If
+// drop.p > 0 also writes Pd = P * keep / (1-p) (row r of replica-stacked Pd reads P row r).
+int k_softmax_rows(float* S, float* Pd, long rows, int cols, DropKey drop, hipStream_t st);
+// dP (in: d(Pd) [rows, cols]) -> dS = P * (dP_eff - sum(dP_eff*P)) * scale, in place
+int k_softmax_bwd_rows(float* dP, const float* P, long rows, int cols, float scale, DropKey drop, hipStream_t st);
+
+// r = x[row % x_rows] + drop(res[row]) ; y = LayerNorm(r)*g + b ; res <- r ; stats[row] = (mean, rstd)
+int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g, const float* b, float* y,
+                        float* stats, long rows, int E, DropKey drop, hipStream_t st);
+// dr = LN backward of dy wrt r (r, stats saved) ; dgamma/dbeta accumulated atomically.
+// dres_out (may be null) = drop-masked dr (gradient w.r.t. the un-dropped `res` branch)
+int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr,
+                    float* dres_out, float* dgamma, float* dbeta, long rows, int E, DropKey drop, hipStream_t st);
+
+// out[n] += sum_rows X[r, n]
+int k_colsum(const float* X, long rows, int N, long ld, float* out, hipStream_t st);
+// out[n] += sum_rows X[r,n] * (ref[r,n] > 0 ? 1 : slope)
+int k_colsum_masked(const float* X, const float* ref, long rows, int N, float slope, float* out, hipStream_t st);
+// y *= (ref > 0 ? 1 : slope) * scale   (activation backward using the POST-activation value)
+int k_act_bwd(float* y, const float* ref, long n, float slope, float scale, hipStream_t st);
+// y = act(y + bias[col])   (bias may be null)
+int k_bias_act(float* y, const float* bias, long rows, int N, int act, float slope, hipStream_t st);
+// x *= keep/(1-p)
+int k_dropout(float* x, long n, DropKey drop, hipStream_t st);
+// y[r,:] *= s[r]
+int k_rowscale(float* y, const float* s, long rows, int N, hipStream_t st);
+// out[r,n] = (ref[r,n] > 0 ? 1 : slope) * w[n]
+int k_mask_times_vec(float* out, const float* ref, const float* w, long rows, int N, float slope, hipStream_t st);
+
+// single-query multi-head attention (query length 1): q [B,E] (projected), kv [B,S,2E] (K|V projected)
+// mask [B,S] bytes (nonzero = ignore).  probs [B,nh,S], ctx [B,E].
+// mask row of sample b is b % mask_B (replica-stacked batches share the mask of the original batch)
+int k_sq_attn_fwd(const float* q, const float* kv, const uint8_t* mask, int mask_B, float* probs, float* ctx,
+                  int B, int S, int E, int nh, hipStream_t st);
+// dctx [B,E] -> dq [B,E] (overwritten), dkv [B,S,2E] (overwritten)
+int k_sq_attn_bwd(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv,
+                  int B, int S, int E, int nh, hipStream_t st);
+
+// out[i] = sum_{r<R} in[r*n + i]   (fold replica-stacked gradients)
+int k_fold(float* out, const float* in, long n, int R, hipStream_t st);
+// out[(b*P+p), :] = seq[b, 1+p, :]   (drop the CLS row: [B,P+1,E] -> [B*P,E])
+int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st);
+// out = in * keep/(1-p)   (re-materialise dropped attention probabilities in backward)
+int k_dropout_copy(float* out, const float* in, long n, DropKey drop, hipStream_t st);
+
+// critic outputs -> losses and seeds: losses[0]+= -mean(d_true) ; losses[1] += mean(d_fake)
+// (d layout: [2B] = fake rows then real rows) ; seed[r] = +1/B (fake) / -1/B (real)
+int k_critic_loss_seed(const float* d, float* seed, float* losses, int B, hipStream_t st);
+// generator: losses[3] = -mean(d_fake) ; seed[r] = -1/B
+int k_gen_loss_seed(const float* d, float* seed, float* losses, int B, hipStream_t st);
+
+// h1_hat = alpha*P_real + (1-alpha)*P_fake  (P rows: [fake(B) ; real(B)], alpha [B])
+int k_lerp_rows(const float* Pfr, const float* alpha, float* out, int B, int H, hipStream_t st);
+// x_hat = alpha*x_real + (1-alpha)*x_fake  (xfr rows: [fake(B) ; real(B)])
+int k_lerp_genes(const float* xfr, const float* alpha, float* out, int B, int G, hipStream_t st);
+// nrm2[r] = sum_n X[r,n]^2
+int k_row_sumsq(const float* X, float* out, long rows, int N, hipStream_t st);
+// coef[r] = gp_weight*(2/B)*(nrm-1)/nrm ; losses[2] += mean((nrm-1)^2)
+int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_weight, hipStream_t st);
+
+// optimiser ---------------------------------------------------------------------------------------
+int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
+enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };
+// clip coefficient = min(1, max_norm/(sqrt(*sumsq)+1e-6)) when max_norm > 0, else 1.  grad_scale is
+// an extra factor applied to every gradient first (1/world_size after a sum all-reduce).
+int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
+               const float* sumsq, float grad_scale, int step_t, hipStream_t st);
+
+}  // namespace gg

@@ -1,0 +1,765 @@
+// Row-wise / elementwise kernels (gfx950).  Memory-bound helpers around the MFMA GEMMs: every
+// kernel reads and writes contiguous rows with consecutive lanes on consecutive addresses; rows are
+// owned by one 64-lane wave so all reductions are wave shuffles (no LDS round trips, no atomics
+// except the cross-row parameter-gradient sums).
+#include "kernels.h"
+
+namespace gg {
+
+namespace {
+constexpr int TPB = 256;
+inline unsigned nblocks(long n, int per = TPB, long cap = 1 << 20) {
+    long b = (n + per - 1) / per;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- dropout stream -----------------------------------------------------------------------------
+// keep(i) for element i of a (seed, site, call) stream: two rounds of the murmur3 32-bit finaliser
+// over the element counter, keyed per stream.  Counter based => the backward pass regenerates the
+// identical mask from (key, i) and no mask tensor is ever stored.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float drop_factor(const DropKey& k, uint64_t i, float keep_scale) {
+    uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+    uint32_t h = fmix32(lo * 0x9E3779B1u + k.k0);
+    h = fmix32(h ^ k.k1 ^ (hi * 0x7F4A7C15u));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u >= k.p ? keep_scale : 0.f;
+}
+}  // namespace
+
+DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call) {
+    DropKey k;
+    k.p = p;
+    auto mix = [](uint64_t x) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    };
+    uint64_t a = mix(seed ^ (0x9E3779B97F4A7C15ULL * (site + 1)));
+    uint64_t b = mix(a ^ (0xD1B54A32D192ED03ULL * ((uint64_t)call + 1)));
+    k.k0 = (uint32_t)b;
+    k.k1 = (uint32_t)(b >> 32);
+    return k;
+}
+
+#define GG_LAUNCH_CHECK()             \
+    GG_CHECK_HIP(hipGetLastError()); \
+    return 0
+
+// ---- trivial elementwise ------------------------------------------------------------------------
+__global__ void fill_k(float* x, long n, float v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+int k_fill(float* x, long n, float v, hipStream_t st) {
+    if (n <= 0) return 0;
+    fill_k<<<nblocks(n, TPB, 4096), TPB, 0, st>>>(x, n, v);
+    GG_LAUNCH_CHECK();
+}
+int k_copy(float* dst, const float* src, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    GG_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+__global__ void copy_rows_bcast_k(float* dst, const float* src, long rows, long src_rows, int cols) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[i] = src[(r % src_rows) * cols + c];
+    }
+}
+int k_copy_rows_bcast(float* dst, const float* src, long rows, long src_rows, int cols, hipStream_t st) {
+    copy_rows_bcast_k<<<nblocks(rows * cols, TPB, 8192), TPB, 0, st>>>(dst, src, rows, src_rows, cols);
+    GG_LAUNCH_CHECK();
+}
+__global__ void axpy_k(float* y, const float* x, float a, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+int k_axpy(float* y, const float* x, float a, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    axpy_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(y, x, a, n);
+    GG_LAUNCH_CHECK();
+}
+__global__ void add_bcast_rows_k(float* y, const float* x, long rows, long x_rows, int cols) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        y[i] += x[(r % x_rows) * cols + (i - r * cols)];
+    }
+}
+int k_add_bcast_rows(float* y, const float* x, long rows, long x_rows, int cols, hipStream_t st) {
+    add_bcast_rows_k<<<nblocks(rows * cols, TPB, 8192), TPB, 0, st>>>(y, x, rows, x_rows, cols);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- FiLM ---------------------------------------------------------------------------------------
+__global__ void film_act_fwd_k(const float* pre, float* gb, int B, int Dp) {
+    const long n = (long)B * 2 * Dp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (2 * Dp));
+        const float v = pre[i];
+        gb[i] = (c < Dp) ? tanhf(v) : fminf(fmaxf(v, -5.f), 5.f);
+    }
+}
+int k_film_act_fwd(const float* gb_pre, float* gb, int B, int Dp, hipStream_t st) {
+    film_act_fwd_k<<<nblocks((long)B * 2 * Dp), TPB, 0, st>>>(gb_pre, gb, B, Dp);
+    GG_LAUNCH_CHECK();
+}
+__global__ void film_act_bwd_k(float* dgb, const float* gb, const float* pre, int B, int Dp) {
+    const long n = (long)B * 2 * Dp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (2 * Dp));
+        const float d = dgb[i];
+        if (c < Dp) {
+            const float g = gb[i];
+            dgb[i] = d * (1.f - g * g);
+        } else {
+            const float v = pre[i];
+            dgb[i] = (v >= -5.f && v <= 5.f) ? d : 0.f;
+        }
+    }
+}
+int k_film_act_bwd(float* dgb, const float* gb, const float* gb_pre, int B, int Dp, hipStream_t st) {
+    film_act_bwd_k<<<nblocks((long)B * 2 * Dp), TPB, 0, st>>>(dgb, gb, gb_pre, B, Dp);
+    GG_LAUNCH_CHECK();
+}
+__global__ void film_mod_k(const float* patches, const float* gb, float* mod, int B, int P, int Dp) {
+    const long n = (long)B * P * Dp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % Dp);
+        const long b = i / ((long)P * Dp);
+        mod[i] = gb[b * 2 * Dp + d] * patches[i] + gb[b * 2 * Dp + Dp + d];
+    }
+}
+int k_film_mod(const float* patches, const float* gb, float* mod, int B, int P, int Dp, hipStream_t st) {
+    film_mod_k<<<nblocks((long)B * P * Dp, TPB, 16384), TPB, 0, st>>>(patches, gb, mod, B, P, Dp);
+    GG_LAUNCH_CHECK();
+}
+// one block per (b, chunk of 256 channels): thread owns channel d, loops over p (coalesced across d)
+__global__ void film_bwd_reduce_k(const float* dmod, const float* patches, float* dgb, int B, int P, int Dp) {
+    const int b = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= Dp) return;
+    float sg = 0.f, sb = 0.f;
+    const long base = (long)b * P * Dp + d;
+    for (int p = 0; p < P; ++p) {
+        const float dm = dmod[base + (long)p * Dp];
+        sg += dm * patches[base + (long)p * Dp];
+        sb += dm;
+    }
+    dgb[(long)b * 2 * Dp + d] = sg;
+    dgb[(long)b * 2 * Dp + Dp + d] = sb;
+}
+int k_film_bwd_reduce(const float* dmod, const float* patches, float* dgb, int B, int P, int Dp, hipStream_t st) {
+    dim3 grid((Dp + TPB - 1) / TPB, B);
+    film_bwd_reduce_k<<<grid, TPB, 0, st>>>(dmod, patches, dgb, B, P, Dp);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- CLS row / mask -----------------------------------------------------------------------------
+__global__ void write_cls_k(float* seq, const float* cls, int B, int S, int E) {
+    const long n = (long)B * E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / E;
+        const int e = (int)(i % E);
+        seq[b * S * E + e] = cls[e];
+    }
+}
+int k_write_cls(float* seq, const float* cls, int B, int S, int E, hipStream_t st) {
+    write_cls_k<<<nblocks((long)B * E), TPB, 0, st>>>(seq, cls, B, S, E);
+    GG_LAUNCH_CHECK();
+}
+__global__ void cls_grad_k(const float* dseq, float* dcls, int B, int S, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dseq[(long)b * S * E + e];
+    dcls[e] += s;
+}
+int k_cls_grad(const float* dseq, float* dcls, int B, int S, int E, hipStream_t st) {
+    cls_grad_k<<<(E + 63) / 64, 64, 0, st>>>(dseq, dcls, B, S, E);
+    GG_LAUNCH_CHECK();
+}
+__global__ void build_mask_k(const uint8_t* pad, uint8_t* out, int B, int P) {
+    const long n = (long)B * (P + 1);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / (P + 1);
+        const int s = (int)(i % (P + 1));
+        out[i] = (s == 0) ? 0 : (pad[b * P + s - 1] ? 1 : 0);
+    }
+}
+int k_build_mask(const uint8_t* pad, uint8_t* mask_out, int B, int P, hipStream_t st) {
+    build_mask_k<<<nblocks((long)B * (P + 1)), TPB, 0, st>>>(pad, mask_out, B, P);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- softmax over rows (one wave per row, row cached in LDS) ----------------------------------------
+constexpr int SM_MAXC = 2048;
+__global__ __launch_bounds__(TPB) void softmax_rows_k(float* S, float* Pd, long rows, int cols, DropKey drop) {
+    __shared__ float buf[4][SM_MAXC];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
+        float* s = S + row * cols;
+        float m = -INFINITY;
+        for (int c = lane; c < cols; c += 64) {
+            const float v = s[c];
+            buf[wave][c] = v;
+            m = fmaxf(m, v);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float e = __expf(buf[wave][c] - m);
+            buf[wave][c] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int c = lane; c < cols; c += 64) {
+            const float p = buf[wave][c] * inv;
+            s[c] = p;
+            if (Pd) Pd[row * cols + c] = p * drop_factor(drop, (uint64_t)row * cols + c, ks);
+        }
+    }
+}
+int k_softmax_rows(float* S, float* Pd, long rows, int cols, DropKey drop, hipStream_t st) {
+    GG_REQUIRE(cols <= SM_MAXC, "softmax row too long");
+    if (drop.p <= 0.f) Pd = nullptr;
+    softmax_rows_k<<<nblocks(rows, 4, 65535), TPB, 0, st>>>(S, Pd, rows, cols, drop);
+    GG_LAUNCH_CHECK();
+}
+__global__ __launch_bounds__(TPB) void softmax_bwd_rows_k(float* dP, const float* P, long rows, int cols, float scale,
+                                                          DropKey drop) {
+    __shared__ float buf[4][SM_MAXC];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
+        float* d = dP + row * cols;
+        const float* p = P + row * cols;
+        float dot = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            float g = d[c];
+            if (drop.p > 0.f) g *= drop_factor(drop, (uint64_t)row * cols + c, ks);
+            buf[wave][c] = g;
+            dot += g * p[c];
+        }
+        dot = wave_sum(dot);
+        for (int c = lane; c < cols; c += 64) d[c] = p[c] * (buf[wave][c] - dot) * scale;
+    }
+}
+int k_softmax_bwd_rows(float* dP, const float* P, long rows, int cols, float scale, DropKey drop, hipStream_t st) {
+    GG_REQUIRE(cols <= SM_MAXC, "softmax row too long");
+    softmax_bwd_rows_k<<<nblocks(rows, 4, 65535), TPB, 0, st>>>(dP, P, rows, cols, scale, drop);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- residual add + LayerNorm (one wave per row; NJ = ceil(E/64) values per lane) ---------------------
+constexpr float LN_EPS = 1e-5f;
+template <int NJ>
+__global__ __launch_bounds__(TPB) void add_ln_fwd_k(const float* x, long x_rows, float* res, const float* g,
+                                                     const float* b, float* y, float* stats, long rows, int E,
+                                                     DropKey drop) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
+        const float* xr = x + (row % x_rows) * E;
+        float* rr = res + row * E;
+        float v[NJ];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            float t = 0.f;
+            if (c < E) {
+                float rv = rr[c];
+                if (drop.p > 0.f) rv *= drop_factor(drop, (uint64_t)row * E + c, ks);
+                t = xr[c] + rv;
+                rr[c] = t;
+            }
+            v[j] = t;
+            sum += t;
+        }
+        const float mean = wave_sum(sum) / E;
+        float var = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            const float dlt = (c < E) ? v[j] - mean : 0.f;
+            var += dlt * dlt;
+        }
+        var = wave_sum(var) / E;
+        const float rstd = rsqrtf(var + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < E) y[row * E + c] = (v[j] - mean) * rstd * g[c] + b[c];
+        }
+        if (lane == 0) {
+            stats[2 * row] = mean;
+            stats[2 * row + 1] = rstd;
+        }
+    }
+}
+int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g, const float* b, float* y,
+                        float* stats, long rows, int E, DropKey drop, hipStream_t st) {
+    const unsigned nb = nblocks(rows, 4, 65535);
+#define GG_LN_FWD(NJ) add_ln_fwd_k<NJ><<<nb, TPB, 0, st>>>(x, x_rows, res, g, b, y, stats, rows, E, drop)
+    if (E <= 64) GG_LN_FWD(1);
+    else if (E <= 128) GG_LN_FWD(2);
+    else if (E <= 256) GG_LN_FWD(4);
+    else if (E <= 512) GG_LN_FWD(8);
+    else if (E <= 1024) GG_LN_FWD(16);
+    else { set_error("LayerNorm width > 1024 unsupported"); return -2; }
+#undef GG_LN_FWD
+    GG_LAUNCH_CHECK();
+}
+
+template <int NJ>
+__global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r, const float* stats, const float* g,
+                                                 float* dr, float* dres, float* dgamma, float* dbeta, long rows, int E,
+                                                 DropKey drop) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    float pg[NJ], pb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) pg[j] = pb[j] = 0.f;
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float xh[NJ], dxh[NJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            xh[j] = dxh[j] = 0.f;
+            if (c < E) {
+                const float d = dy[row * E + c];
+                xh[j] = (r[row * E + c] - mean) * rstd;
+                dxh[j] = d * g[c];
+                pg[j] += d * xh[j];
+                pb[j] += d;
+                s1 += dxh[j];
+                s2 += dxh[j] * xh[j];
+            }
+        }
+        s1 = wave_sum(s1) / E;
+        s2 = wave_sum(s2) / E;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < E) {
+                const float v = rstd * (dxh[j] - s1 - xh[j] * s2);
+                dr[row * E + c] = v;
+                if (dres) dres[row * E + c] = drop.p > 0.f ? v * drop_factor(drop, (uint64_t)row * E + c, ks) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < E) {
+            atomicAdd(&dgamma[c], pg[j]);
+            atomicAdd(&dbeta[c], pb[j]);
+        }
+    }
+}
+int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, float* dres_out,
+                    float* dgamma, float* dbeta, long rows, int E, DropKey drop, hipStream_t st) {
+    const unsigned nb = nblocks(rows, 4 * 16, 4096);   // >=16 rows per wave so the atomics are amortised
+#define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dgamma, dbeta, rows, E, drop)
+    if (E <= 64) GG_LN_BWD(1);
+    else if (E <= 128) GG_LN_BWD(2);
+    else if (E <= 256) GG_LN_BWD(4);
+    else if (E <= 512) GG_LN_BWD(8);
+    else if (E <= 1024) GG_LN_BWD(16);
+    else { set_error("LayerNorm width > 1024 unsupported"); return -2; }
+#undef GG_LN_BWD
+    GG_LAUNCH_CHECK();
+}
+
+// ---- column sums (bias gradients) ------------------------------------------------------------------
+constexpr int CS_ROWS = 128;
+__global__ void colsum_k(const float* X, const float* ref, long rows, int N, long ld, float slope, float* out) {
+    const long r0 = (long)blockIdx.x * CS_ROWS;
+    const long r1 = min(rows, r0 + CS_ROWS);
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        float s = 0.f;
+        if (ref) {
+            for (long r = r0; r < r1; ++r) s += X[r * ld + c] * (ref[r * ld + c] > 0.f ? 1.f : slope);
+        } else {
+            for (long r = r0; r < r1; ++r) s += X[r * ld + c];
+        }
+        atomicAdd(&out[c], s);
+    }
+}
+int k_colsum(const float* X, long rows, int N, long ld, float* out, hipStream_t st) {
+    colsum_k<<<(unsigned)((rows + CS_ROWS - 1) / CS_ROWS), TPB, 0, st>>>(X, nullptr, rows, N, ld, 0.f, out);
+    GG_LAUNCH_CHECK();
+}
+int k_colsum_masked(const float* X, const float* ref, long rows, int N, float slope, float* out, hipStream_t st) {
+    colsum_k<<<(unsigned)((rows + CS_ROWS - 1) / CS_ROWS), TPB, 0, st>>>(X, ref, rows, N, N, slope, out);
+    GG_LAUNCH_CHECK();
+}
+
+__global__ void act_bwd_k(float* y, const float* ref, long n, float slope, float scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] *= (ref[i] > 0.f ? 1.f : slope) * scale;
+}
+int k_act_bwd(float* y, const float* ref, long n, float slope, float scale, hipStream_t st) {
+    act_bwd_k<<<nblocks(n, TPB, 16384), TPB, 0, st>>>(y, ref, n, slope, scale);
+    GG_LAUNCH_CHECK();
+}
+__global__ void bias_act_k(float* y, const float* bias, long rows, int N, int act, float slope) {
+    const long n = rows * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = y[i];
+        if (bias) v += bias[i % N];
+        if (act == ACT_LRELU) v = v > 0.f ? v : slope * v;
+        y[i] = v;
+    }
+}
+int k_bias_act(float* y, const float* bias, long rows, int N, int act, float slope, hipStream_t st) {
+    bias_act_k<<<nblocks(rows * N, TPB, 16384), TPB, 0, st>>>(y, bias, rows, N, act, slope);
+    GG_LAUNCH_CHECK();
+}
+__global__ void dropout_k(float* x, long n, DropKey drop) {
+    const float ks = 1.f / (1.f - drop.p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] *= drop_factor(drop, (uint64_t)i, ks);
+}
+int k_dropout(float* x, long n, DropKey drop, hipStream_t st) {
+    if (drop.p <= 0.f || n <= 0) return 0;
+    dropout_k<<<nblocks(n, TPB, 16384), TPB, 0, st>>>(x, n, drop);
+    GG_LAUNCH_CHECK();
+}
+__global__ void rowscale_k(float* y, const float* s, long rows, int N) {
+    const long n = rows * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] *= s[i / N];
+}
+int k_rowscale(float* y, const float* s, long rows, int N, hipStream_t st) {
+    rowscale_k<<<nblocks(rows * N, TPB, 16384), TPB, 0, st>>>(y, s, rows, N);
+    GG_LAUNCH_CHECK();
+}
+__global__ void mask_times_vec_k(float* out, const float* ref, const float* w, long rows, int N, float slope) {
+    const long n = rows * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (ref[i] > 0.f ? 1.f : slope) * w[i % N];
+}
+int k_mask_times_vec(float* out, const float* ref, const float* w, long rows, int N, float slope, hipStream_t st) {
+    mask_times_vec_k<<<nblocks(rows * N), TPB, 0, st>>>(out, ref, w, rows, N, slope);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- single-query attention ------------------------------------------------------------------------
+// block = one sample b; wave w handles heads w, w+4, ...; scores of one head live in LDS.
+constexpr int SQ_MAXS = 2048;
+__global__ __launch_bounds__(TPB) void sq_attn_fwd_k(const float* q, const float* kv, const uint8_t* mask, int mask_B,
+                                                      float* probs, float* ctx, int S, int E, int nh) {
+    __shared__ float sc[4][SQ_MAXS];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dh = E / nh;
+    const float scale = rsqrtf((float)dh);
+    const float* kvb = kv + (long)b * S * 2 * E;
+    for (int h = wave; h < nh; h += 4) {
+        const float* qh = q + (long)b * E + h * dh;
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) {
+            const float* kr = kvb + (long)s * 2 * E + h * dh;
+            float dot = 0.f;
+            for (int d = 0; d < dh; ++d) dot += qh[d] * kr[d];
+            dot *= scale;
+            if (mask && mask[(long)(b % mask_B) * S + s]) dot = -INFINITY;
+            sc[wave][s] = dot;
+            m = fmaxf(m, dot);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float e = __expf(sc[wave][s] - m);
+            sc[wave][s] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int s = lane; s < S; s += 64) {
+            const float p = sc[wave][s] * inv;
+            sc[wave][s] = p;
+            probs[((long)b * nh + h) * S + s] = p;
+        }
+        // wave-private LDS row: make the writes above visible to all lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < dh; d += 64) {
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) acc += sc[wave][s] * kvb[(long)s * 2 * E + E + h * dh + d];
+            ctx[(long)b * E + h * dh + d] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+int k_sq_attn_fwd(const float* q, const float* kv, const uint8_t* mask, int mask_B, float* probs, float* ctx, int B,
+                  int S, int E, int nh, hipStream_t st) {
+    GG_REQUIRE(S <= SQ_MAXS, "single-query attention: too many keys");
+    sq_attn_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S, E, nh);
+    GG_LAUNCH_CHECK();
+}
+__global__ __launch_bounds__(TPB) void sq_attn_bwd_k(const float* dctx, const float* q, const float* kv,
+                                                      const float* probs, float* dq, float* dkv, int S, int E, int nh) {
+    __shared__ float ds[4][SQ_MAXS];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dh = E / nh;
+    const float scale = rsqrtf((float)dh);
+    const float* kvb = kv + (long)b * S * 2 * E;
+    float* dkvb = dkv + (long)b * S * 2 * E;
+    for (int h = wave; h < nh; h += 4) {
+        const float* dc = dctx + (long)b * E + h * dh;
+        const float* qh = q + (long)b * E + h * dh;
+        const float* ph = probs + ((long)b * nh + h) * S;
+        float dot = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float* vr = kvb + (long)s * 2 * E + E + h * dh;
+            float dp = 0.f;
+            for (int d = 0; d < dh; ++d) dp += dc[d] * vr[d];
+            ds[wave][s] = dp;
+            dot += dp * ph[s];
+        }
+        dot = wave_sum(dot);
+        for (int s = lane; s < S; s += 64) {
+            const float p = ph[s];
+            const float g = p * (ds[wave][s] - dot) * scale;     // d(score_s)
+            ds[wave][s] = g;
+            float* dkr = dkvb + (long)s * 2 * E + h * dh;
+            float* dvr = dkr + E;
+            for (int d = 0; d < dh; ++d) {
+                dkr[d] = g * qh[d];
+                dvr[d] = p * dc[d];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < dh; d += 64) {
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) acc += ds[wave][s] * kvb[(long)s * 2 * E + h * dh + d];
+            dq[(long)b * E + h * dh + d] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+int k_sq_attn_bwd(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv, int B,
+                  int S, int E, int nh, hipStream_t st) {
+    GG_REQUIRE(S <= SQ_MAXS, "single-query attention: too many keys");
+    sq_attn_bwd_k<<<B, TPB, 0, st>>>(dctx, q, kv, probs, dq, dkv, S, E, nh);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- replica fold / patch-row gather / dropout copy ---------------------------------------------------
+__global__ void fold_k(float* out, const float* in, long n, int R) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += in[(long)r * n + i];
+        out[i] = s;
+    }
+}
+int k_fold(float* out, const float* in, long n, int R, hipStream_t st) {
+    fold_k<<<nblocks(n, TPB, 16384), TPB, 0, st>>>(out, in, n, R);
+    GG_LAUNCH_CHECK();
+}
+__global__ void gather_patch_rows_k(float* out, const float* seq, int B, int P, int E) {
+    const long n = (long)B * P * E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / E;
+        const int e = (int)(i - row * E);
+        const long b = row / P;
+        out[i] = seq[(row + b + 1) * E + e];
+    }
+}
+int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st) {
+    gather_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(out, seq, B, P, E);
+    GG_LAUNCH_CHECK();
+}
+__global__ void dropout_copy_k(float* out, const float* in, long n, DropKey drop) {
+    const float ks = 1.f / (1.f - drop.p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = in[i] * drop_factor(drop, (uint64_t)i, ks);
+}
+int k_dropout_copy(float* out, const float* in, long n, DropKey drop, hipStream_t st) {
+    dropout_copy_k<<<nblocks(n, TPB, 16384), TPB, 0, st>>>(out, in, n, drop);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- losses / seeds ----------------------------------------------------------------------------------
+__global__ void critic_loss_seed_k(const float* d, float* seed, float* losses, int B) {
+    float sf = 0.f, sr = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        sf += d[i];
+        sr += d[B + i];
+        seed[i] = 1.f / B;
+        seed[B + i] = -1.f / B;
+    }
+    __shared__ float red[2][TPB / 64];
+    sf = wave_sum(sf);
+    sr = wave_sum(sr);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sf;
+        red[1][threadIdx.x >> 6] = sr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) {
+            a += red[0][w];
+            c += red[1][w];
+        }
+        losses[0] += -c / B;   // mean(-d_true)
+        losses[1] += a / B;    // mean(d_fake)
+    }
+}
+int k_critic_loss_seed(const float* d, float* seed, float* losses, int B, hipStream_t st) {
+    critic_loss_seed_k<<<1, TPB, 0, st>>>(d, seed, losses, B);
+    GG_LAUNCH_CHECK();
+}
+__global__ void gen_loss_seed_k(const float* d, float* seed, float* losses, int B) {
+    float sf = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        sf += d[i];
+        seed[i] = -1.f / B;
+    }
+    __shared__ float red[TPB / 64];
+    sf = wave_sum(sf);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) a += red[w];
+        losses[3] += -a / B;
+    }
+}
+int k_gen_loss_seed(const float* d, float* seed, float* losses, int B, hipStream_t st) {
+    gen_loss_seed_k<<<1, TPB, 0, st>>>(d, seed, losses, B);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- gradient penalty helpers ------------------------------------------------------------------------
+__global__ void lerp_rows_k(const float* Pfr, const float* alpha, float* out, int B, int H) {
+    const long n = (long)B * H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = alpha[i / H];
+        out[i] = a * Pfr[n + i] + (1.f - a) * Pfr[i];
+    }
+}
+int k_lerp_rows(const float* Pfr, const float* alpha, float* out, int B, int H, hipStream_t st) {
+    lerp_rows_k<<<nblocks((long)B * H, TPB, 16384), TPB, 0, st>>>(Pfr, alpha, out, B, H);
+    GG_LAUNCH_CHECK();
+}
+int k_lerp_genes(const float* xfr, const float* alpha, float* out, int B, int G, hipStream_t st) {
+    return k_lerp_rows(xfr, alpha, out, B, G, st);
+}
+__global__ __launch_bounds__(TPB) void row_sumsq_k(const float* X, float* out, long rows, int N) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
+        float s = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float v = X[row * N + c];
+            s += v * v;
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[row] = s;
+    }
+}
+int k_row_sumsq(const float* X, float* out, long rows, int N, hipStream_t st) {
+    row_sumsq_k<<<nblocks(rows, 4, 65535), TPB, 0, st>>>(X, out, rows, N);
+    GG_LAUNCH_CHECK();
+}
+__global__ void gp_coef_k(const float* nrm2, float* coef, float* losses, int B, float w) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float n = sqrtf(nrm2[i]);
+        const float d = n - 1.f;
+        acc += d * d;
+        coef[i] = n > 0.f ? w * (2.f / B) * d / n : 0.f;
+    }
+    __shared__ float red[TPB / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int k = 0; k < TPB / 64; ++k) a += red[k];
+        losses[2] += a / B;
+    }
+}
+int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_weight, hipStream_t st) {
+    gp_coef_k<<<1, TPB, 0, st>>>(nrm2, coef, losses, B, gp_weight);
+    GG_LAUNCH_CHECK();
+}
+
+// ---- optimiser -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void sumsq_k(const float* x, long n, float* out) {
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        s += v * v;
+    }
+    __shared__ float red[TPB / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int k = 0; k < TPB / 64; ++k) a += red[k];
+        atomicAdd(out, a);
+    }
+}
+int k_sumsq(const float* x, long n, float* out, hipStream_t st) {
+    sumsq_k<<<nblocks(n, TPB * 8, 1024), TPB, 0, st>>>(x, n, out);
+    GG_LAUNCH_CHECK();
+}
+__global__ void opt_step_k(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
+                           const float* sumsq, float grad_scale, float bc1, float bc2s) {
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+        const float total = sqrtf(*sumsq) * grad_scale;
+        coef *= fminf(1.f, max_norm / (total + 1e-6f));
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * coef;
+        float p = w[i];
+        if (kind == OPT_RMSPROP) {
+            const float sq = 0.99f * s1[i] + 0.01f * gr * gr;
+            s1[i] = sq;
+            p -= lr * gr / (sqrtf(sq) + 1e-8f);
+        } else {
+            if (kind == OPT_ADAMW) p *= 1.f - lr * 0.01f;
+            const float m = 0.9f * s1[i] + 0.1f * gr;
+            const float v = 0.99f * s2[i] + 0.01f * gr * gr;
+            s1[i] = m;
+            s2[i] = v;
+            p -= (lr / bc1) * m / (sqrtf(v) / bc2s + 1e-8f);
+        }
+        w[i] = p;
+    }
+}
+int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
+               const float* sumsq, float grad_scale, int step_t, hipStream_t st) {
+    const float bc1 = 1.f - powf(0.9f, (float)step_t);
+    const float bc2s = sqrtf(1.f - powf(0.99f, (float)step_t));
+    opt_step_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(w, g, s1, s2, n, kind, lr, max_norm, sumsq, grad_scale, bc1, bc2s);
+    GG_LAUNCH_CHECK();
+}
+
+}  // namespace gg

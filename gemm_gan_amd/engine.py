@@ -1,0 +1,182 @@
+"""Thin torch-side owner of the device buffers the C-ABI engine works on.
+
+PyTorch is plumbing here: it allocates HBM (flat parameter / gradient / optimiser-state buffers and
+one workspace arena), provides the HIP stream, and runs ``torch.distributed`` for the data-parallel
+gradient all-reduce.  All arithmetic of the hot path happens in libgemmgan.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine = both networks + trainer state for one GPU (one process per GPU)."""
+
+    def __init__(self, *, n_genes, latent_dims, embedding_dims, hidden_dims, text_dims, patch_dims,
+                 n_heads=4, n_layers=2, negative_slope=0.0, dropout=0.1, lr_d=5e-4, lr_g=5e-4,
+                 optimizer="rms_prop", gp_weight=10.0, clip_d=10.0, clip_g=2.0, max_batch=8, max_patches=256,
+                 max_text_tokens=1, seed=0, device="cuda:0"):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("gemm_gan_amd needs a ROCm GPU (cuda:N device); there is no CPU fallback")
+        self.cfg = L.GGConfig(n_genes, latent_dims, embedding_dims, hidden_dims, text_dims, patch_dims, n_heads,
+                              n_layers, negative_slope, dropout, lr_d, lr_g, L.OPT_KINDS[optimizer.lower()], gp_weight,
+                              clip_d if clip_d else 0.0, clip_g if clip_g else 0.0, max_batch, max_patches,
+                              max_text_tokens, seed)
+        self.h = C.c_void_p()
+        L.check(self.lib.gg_create(C.byref(self.cfg), C.byref(self.h)))
+        self.layout = {r: self._read_layout(r) for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC)}
+        self.flat: Dict[int, Dict[str, torch.Tensor]] = {}
+        with torch.cuda.device(self.device):
+            for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+                n = int(self.lib.gg_flat_numel(self.h, r))
+                bufs = {k: torch.zeros(n, dtype=torch.float32, device=self.device) for k in ("w", "g", "s1", "s2")}
+                self.flat[r] = bufs
+                L.check(self.lib.gg_bind_net(self.h, r, _ptr(bufs["w"]), _ptr(bufs["g"]), _ptr(bufs["s1"]), _ptr(bufs["s2"])))
+            self._alloc_workspace()
+            self.losses = torch.zeros(L.N_LOSSES, dtype=torch.float32, device=self.device)
+        self.dropout = float(dropout)
+
+    # -- construction helpers ------------------------------------------------------------------
+    def _read_layout(self, role):
+        out = {}
+        for i in range(self.lib.gg_param_count(self.h, role)):
+            off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int32()
+            shape = (C.c_int32 * 3)()
+            L.check(self.lib.gg_param_info(self.h, role, i, C.byref(off), C.byref(numel), C.byref(ndim), shape))
+            out[self.lib.gg_param_name(self.h, role, i).decode()] = (off.value, numel.value, tuple(shape[:ndim.value]))
+        return out
+
+    def _alloc_workspace(self):
+        nbytes = int(self.lib.gg_workspace_bytes(self.h))
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        L.check(self.lib.gg_bind_workspace(self.h, C.c_void_p(aligned), C.c_size_t(nbytes)))
+        self.workspace_bytes = nbytes
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameter access ------------------------------------------------------------------------
+    def view(self, role, name, which="w") -> torch.Tensor:
+        off, numel, shape = self.layout[role][name]
+        return self.flat[role][which][off:off + numel].view(shape)
+
+    def load_state(self, role, state: Dict[str, torch.Tensor]):
+        for name in self.layout[role]:
+            self.view(role, name).copy_(state[name].to(self.device, torch.float32))
+
+    def state(self, role, which="w") -> Dict[str, torch.Tensor]:
+        return {name: self.view(role, name, which) for name in self.layout[role]}
+
+    # -- calls ----------------------------------------------------------------------------------------
+    def _cond(self, patches, patch_pad, text, text_pad):
+        for t in (patches, text):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device, "fp32 contiguous GPU tensor expected"
+        if patches.dim() != 3 or text.dim() != 3 or patches.shape[0] != text.shape[0]:
+            raise ValueError("patches [B,P,Dp] / text [B,T,Dt] expected")
+        if patches.shape[2] != self.cfg.patch_dims or text.shape[2] != self.cfg.text_dims:
+            raise ValueError("embedding width mismatch")
+        B, P, T = patches.shape[0], patches.shape[1], text.shape[1]
+        if tuple(patch_pad.shape) != (B, P) or tuple(text_pad.shape) != (B, T):
+            raise ValueError("padding mask shape mismatch")
+        pp = patch_pad.to(torch.uint8).contiguous() if patch_pad.dtype != torch.uint8 else patch_pad.contiguous()
+        tp = text_pad.to(torch.uint8).contiguous() if text_pad.dtype != torch.uint8 else text_pad.contiguous()
+        keep = (patches, pp, text, tp)
+        return L.GGCond(patches.data_ptr(), pp.data_ptr(), text.data_ptr(), tp.data_ptr(), B, P, T), keep
+
+    def forward(self, role, v, patches, patch_pad, text, text_pad, train=False) -> torch.Tensor:
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        width = self.cfg.latent_dims if role == L.ROLE_GENERATOR else self.cfg.n_genes
+        if v.dim() != 2 or v.shape[0] != cond.B or v.shape[1] != width:
+            raise ValueError(f"first input must be [B,{width}]")
+        v = v.to(torch.float32).contiguous()
+        out = torch.empty(cond.B, self.cfg.n_genes if role == L.ROLE_GENERATOR else 1, dtype=torch.float32, device=self.device)
+        L.check(self.lib.gg_forward(self.h, role, _ptr(v), C.byref(cond), _ptr(out), int(train), _stream()))
+        return out
+
+    def critic_backward(self, x_real, z, alpha, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        alpha = alpha.reshape(-1).contiguous()
+        L.check(self.lib.gg_critic_backward(self.h, _ptr(x_real), _ptr(z), _ptr(alpha), C.byref(cond), _ptr(self.losses), _stream()))
+
+    def critic_apply(self, grad_scale=1.0):
+        L.check(self.lib.gg_critic_apply(self.h, C.c_float(grad_scale), _stream()))
+
+    def generator_backward(self, z, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_generator_backward(self.h, _ptr(z), C.byref(cond), _ptr(self.losses), _stream()))
+
+    def generator_apply(self, grad_scale=1.0):
+        L.check(self.lib.gg_generator_apply(self.h, C.c_float(grad_scale), _stream()))
+
+    def train_step(self, x_real, patches, patch_pad, text, text_pad, z_all, alpha_all):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        n_critic = alpha_all.shape[0]
+        assert z_all.shape[0] == n_critic + 1 and z_all.is_contiguous() and alpha_all.is_contiguous()
+        L.check(self.lib.gg_train_step(self.h, _ptr(x_real), C.byref(cond), _ptr(z_all), _ptr(alpha_all), n_critic,
+                                       _ptr(self.losses), _stream()))
+
+    def set_lr(self, role, lr):
+        L.check(self.lib.gg_set_lr(self.h, role, C.c_float(lr)))
+
+    def set_dropout(self, p):
+        L.check(self.lib.gg_set_dropout(self.h, C.c_float(p)))
+        self.dropout = float(p)
+
+    def set_seed(self, seed):
+        L.check(self.lib.gg_set_seed(self.h, C.c_uint64(seed)))
+
+    def debug_buffer(self, name: str) -> torch.Tensor:
+        """Copy of a named internal activation buffer of the last call (tests only)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.gg_debug_buffer(self.h, name.encode(), C.byref(ptr), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        rt = C.CDLL("libamdhip64.so")
+        rc = rt.hipMemcpy(C.c_void_p(out.data_ptr()), ptr, C.c_size_t(4 * n.value), C.c_int(3))   # hipMemcpyDeviceToDevice
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return out
+
+    def profile(self, on: bool):
+        L.check(self.lib.gg_profile_enable(self.h, int(on)))
+
+    def profile_collect(self):
+        """[{name, launches, ms, flops, bytes}] per kernel class since profile(True)."""
+        n = self.lib.gg_profile_collect(self.h)
+        if n < 0:
+            L.check(n)
+        rows = []
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            launches, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            L.check(self.lib.gg_profile_read(self.h, i, name, 128, C.byref(launches), C.byref(ms), C.byref(fl), C.byref(by)))
+            rows.append(dict(name=name.value.decode(), launches=launches.value, ms=ms.value, flops=fl.value, bytes=by.value))
+        return rows
+
+    def launch_count(self):
+        return int(self.lib.gg_launch_count(self.h))

@@ -1,0 +1,392 @@
+"""Drop-in host-side mirror of the reference's hot-path object API, backed by the HIP engine.
+
+Mirrors /root/reference/src/conditional_gan_cross_attention_with_film.py (R:):
+    generator (R:97), discriminator (R:167), WGAN_GP_model (R:236), WGAN_GP (R:256) with
+    init_train (R:320), build_WGAN_GP (R:334), train_disc (R:376), train_gen (R:425), train (R:463),
+    generate_samples (R:601), fit (R:619; training loop, LR schedule and checkpoints only).
+
+Same class names, constructor kwargs, method signatures (including the differing argument orders of
+train_disc / gradient_penalty / forward), tensor conventions (bool masks, True = padded) and
+``state_dict`` keys - including the twelve dead ``patches_transformer_layer.*`` entries (R:114) -
+so a reference checkpoint loads here and vice versa.
+
+What runs where: ``torch.nn`` modules below are PARAMETER CONTAINERS ONLY (they give the reference's
+initialisation, names and ``state_dict`` for free); their storage is re-pointed into the engine's flat
+HBM buffers and their ``forward`` is never called.  Every forward / backward / optimiser computation is
+done by libgemmgan.so.  Without a GPU or without the built library these classes raise.
+
+Not supported (by design): autograd through ``forward`` (training goes through ``WGAN_GP.train*``,
+whose backward is hand-written in the engine); ``is_bn=True`` (never enabled by the reference's
+``__main__``, R:949); ``p_aug != 0`` (raises NameError in the reference, R:401).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .engine import Engine
+
+
+def _block(n_in, n_out, slope):
+    return nn.Sequential(nn.Linear(n_in, n_out), nn.LeakyReLU(negative_slope=slope))
+
+
+class _CondNet(nn.Module):
+    """Parameter container with the reference's attribute names + engine-backed forward."""
+
+    _role = None          # 'generator' | 'discriminator'
+
+    def __init__(self, first_dims, embedding_dims, mlp_dims, text_embedding_dims=768,
+                 patches_embedding_dims=1024, negative_slope=0.0, is_bn=False):
+        super().__init__()
+        if is_bn:
+            raise NotImplementedError("is_bn=True is not part of the accelerated hot path (never enabled upstream)")
+        E = embedding_dims
+        self.embedding_dims = E
+        self.text_embedding_dims = text_embedding_dims
+        self.patches_embedding_dims = patches_embedding_dims
+        self.negative_slope = negative_slope
+        self.is_bn = is_bn
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        # construction order == reference order (R:111-126), so a given torch seed gives the same init
+        self.film_generator = nn.Linear(text_embedding_dims, patches_embedding_dims * 2)
+        self.text_encoder = nn.Linear(text_embedding_dims, E)
+        self.patches_encoder = nn.Linear(patches_embedding_dims, E)
+        self.patches_transformer_layer = nn.TransformerEncoderLayer(
+            d_model=E, nhead=4, dim_feedforward=E * 2, dropout=0.1, activation="relu", batch_first=True)
+        self.patches_cls_token = nn.Parameter(torch.empty(1, 1, E))
+        torch.nn.init.trunc_normal_(self.patches_cls_token, std=0.02)
+        self.patches_transformer = nn.TransformerEncoder(self.patches_transformer_layer, num_layers=2)
+        self.patch2text_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
+        self.text2patch_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
+        self.input_dims = first_dims + E
+        dims = list(mlp_dims)
+        blocks = nn.ModuleList()
+        prev = self.input_dims
+        for d in dims[:-1]:
+            blocks.append(_block(prev, d, negative_slope))
+            prev = d
+        if len(blocks) != 2 or dims[0] != dims[1]:
+            raise NotImplementedError("the engine implements the reference's [H, H, out] MLP heads")
+        setattr(self, self._role, blocks)
+        self.final_layer = nn.Linear(dims[-2], dims[-1])
+        self._engine: Optional[Engine] = None
+        self._engine_role = L.ROLE_GENERATOR if self._role == "generator" else L.ROLE_CRITIC
+
+    # ---- engine binding ---------------------------------------------------------------------
+    def _bind(self, engine: Engine):
+        """Copy current values into the engine's flat buffer and re-point every live parameter at it."""
+        self._engine = engine
+        role = self._engine_role
+        params = dict(self.named_parameters())
+        with torch.no_grad():
+            for name in engine.layout[role]:
+                view = engine.view(role, name)
+                view.copy_(params[name].detach().to(view.device, torch.float32))
+                params[name].data = view
+            for name, p in params.items():           # dead template layer: plain device tensors
+                if name.startswith("patches_transformer_layer."):
+                    p.data = p.data.to(engine.device)
+        return self
+
+    def _require_engine(self) -> Engine:
+        if self._engine is None:
+            raise RuntimeError("network is not bound to a HIP engine; build it through WGAN_GP.build_WGAN_GP() "
+                               "or gemm_gan_amd.standalone_engine(...) (there is no torch/CPU fallback)")
+        return self._engine
+
+    def forward(self, gene_expression, patches, patches_padding_mask, text_tokens, text_padding_mask):
+        eng = self._require_engine()
+        owner = getattr(eng, "_owner", None)
+        if owner is not None:
+            owner._ensure_capacity(patches.shape[0], patches.shape[1], text_tokens.shape[1])
+            eng = owner.engine
+        with torch.no_grad():
+            return eng.forward(self._engine_role, gene_expression.to(eng.device), patches.to(eng.device).contiguous(),
+                               patches_padding_mask.to(eng.device), text_tokens.to(eng.device).contiguous(),
+                               text_padding_mask.to(eng.device), train=self.training)
+
+
+class generator(_CondNet):
+    _role = "generator"
+
+    def __init__(self, latent_dims, embedding_dims, generator_dims, text_embedding_dims=768,
+                 patches_embedding_dims=1024, negative_slope=0.0, is_bn=False):
+        super().__init__(latent_dims, embedding_dims, generator_dims, text_embedding_dims,
+                         patches_embedding_dims, negative_slope, is_bn)
+        self.latent_dims = latent_dims
+        self.generator_dims = generator_dims
+
+
+class discriminator(_CondNet):
+    _role = "discriminator"
+
+    def __init__(self, vector_dims, embedding_dims, discriminator_dims, text_embedding_dims=768,
+                 patches_embedding_dims=1024, negative_slope=0.0, is_bn=False):
+        super().__init__(vector_dims, embedding_dims, discriminator_dims, text_embedding_dims,
+                         patches_embedding_dims, negative_slope, is_bn)
+        self.vector_dims = vector_dims
+        self.discriminator_dims = discriminator_dims
+
+
+def WGAN_GP_model(latent_dims, vector_dims, embedding_dims, generator_dims, discriminator_dims,
+                  text_embedding_dims=768, patches_embedding_dims=1024, negative_slope=0.0, is_bn=False):
+    gen = generator(latent_dims, embedding_dims, generator_dims, text_embedding_dims,
+                    patches_embedding_dims, negative_slope, is_bn)
+    disc = discriminator(vector_dims, embedding_dims, discriminator_dims, text_embedding_dims,
+                         patches_embedding_dims, negative_slope, is_bn)
+    return gen, disc
+
+
+class _EngineOptimizer:
+    """Stand-in for torch.optim.* exposing what fit() touches: mutable param_groups[i]['lr'] (R:651-657)."""
+
+    def __init__(self, kind, lr):
+        self.kind = kind
+        self.param_groups = [{"lr": lr}]
+
+    def zero_grad(self, set_to_none=True):
+        return None          # gradients live in the engine's flat buffer and are rewritten every iteration
+
+
+class WGAN_GP:
+    def __init__(self, input_dims, latent_dims, embedding_dims, generator_dims, discriminator_dims,
+                 text_embedding_dims=768, patches_embedding_dims=1024, negative_slope=0.0, is_bn=False,
+                 lr_d=5e-4, lr_g=5e-4, optimizer="rms_prop", gp_weight=10, p_aug=0, norm_scale=0.5, train=True,
+                 n_critic=5, freq_print=2, freq_compute_test=50, freq_visualize_test=100, patience=10,
+                 normalization="standardize", log2=False, rpm=False, results_dire="",
+                 # --- extensions (keyword-only in spirit; defaults reproduce the reference) ---
+                 dropout=0.1, seed=0, device=None, process_group=None):
+        self.input_dims = input_dims
+        self.latent_dims = latent_dims
+        self.embedding_dims = embedding_dims
+        self.generator_dims = generator_dims
+        self.discriminator_dims = discriminator_dims
+        self.text_embedding_dims = text_embedding_dims
+        self.patches_embedding_dims = patches_embedding_dims
+        self.negative_slope = negative_slope
+        self.is_bn = is_bn
+        self.gp_weight = gp_weight
+        self.isTrain = train
+        self.p_aug = p_aug
+        self.norm_scale = norm_scale
+        self.n_genes = input_dims
+        self.n_critic = n_critic
+        self.freq_print = freq_print
+        self.freq_compute_test = freq_compute_test
+        self.freq_visualize_test = freq_visualize_test
+        self.result_dire = results_dire
+        if results_dire:
+            os.makedirs(self.result_dire, exist_ok=True)
+            self.results_dire_fig = os.path.join(self.result_dire, "figures")
+            os.makedirs(self.results_dire_fig, exist_ok=True)
+        self.lr_d, self.lr_g = lr_d, lr_g
+        self.optimizer = optimizer
+        self.patience = patience
+        if p_aug != 0:
+            raise NotImplementedError("p_aug != 0 raises NameError in the reference (R:401); unsupported")
+        if optimizer.lower() not in L.OPT_KINDS:
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        if device is None:
+            device = "cuda:0" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        self.loss_dict = {"d loss": [], "d real loss": [], "d fake loss": [], "g loss": []}
+        self.normalization, self.log2, self.rpm = normalization, log2, rpm
+        self.dropout = dropout
+        self.seed = seed
+        self.process_group = process_group
+        self.engine: Optional[Engine] = None
+        self.gen = self.disc = None
+        self.optimizer_disc = self.optimizer_gen = None
+
+    # ---- construction (R:334-349, R:320-331) -------------------------------------------------------
+    def build_WGAN_GP(self):
+        self.gen, self.disc = WGAN_GP_model(self.latent_dims, self.input_dims, self.embedding_dims, self.generator_dims,
+                                            self.discriminator_dims, self.text_embedding_dims, self.patches_embedding_dims,
+                                            self.negative_slope, self.is_bn)
+        if self.device.type != "cuda":
+            raise RuntimeError("gemm_gan_amd.WGAN_GP needs a ROCm GPU: there is no CPU fallback "
+                               "(use oracle/torch_oracle.py for CPU checks)")
+        self._make_engine(8, 16, 1)
+
+    def init_train(self):
+        kind = self.optimizer.lower()
+        self.optimizer_disc = _EngineOptimizer(kind, self.lr_d)
+        self.optimizer_gen = _EngineOptimizer(kind, self.lr_g)
+
+    def _make_engine(self, B, P, T):
+        H = self.generator_dims[0]
+        old = self.engine
+        eng = Engine(n_genes=self.input_dims, latent_dims=self.latent_dims, embedding_dims=self.embedding_dims,
+                     hidden_dims=H, text_dims=self.text_embedding_dims, patch_dims=self.patches_embedding_dims,
+                     negative_slope=self.negative_slope, dropout=self.dropout, lr_d=self.lr_d, lr_g=self.lr_g,
+                     optimizer=self.optimizer, gp_weight=float(self.gp_weight), max_batch=B, max_patches=P,
+                     max_text_tokens=T, seed=self.seed, device=self.device)
+        eng._owner = self
+        if old is not None:          # grow: keep parameters, gradients, optimiser state and step counters
+            for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+                for k in ("w", "g", "s1", "s2"):
+                    eng.flat[r][k].copy_(old.flat[r][k])
+                L.check(eng.lib.gg_set_optimizer_step(eng.h, r, old.lib.gg_get_optimizer_step(old.h, r)))
+        self.engine = eng
+        self.gen._bind(eng)
+        self.disc._bind(eng)
+        if old is not None:
+            old.close()
+
+    def reserve(self, batch, patches, tokens):
+        """Size the workspace for the largest minibatch that will be seen (grow-only)."""
+        self._ensure_capacity(batch, patches, tokens)
+
+    def _ensure_capacity(self, B, P, T):
+        c = self.engine.cfg
+        if B > c.max_batch or P > c.max_patches or T > c.max_text_tokens:
+            self._make_engine(max(B, c.max_batch), max(P, c.max_patches), max(T, c.max_text_tokens))
+
+    def _sync_lr(self):
+        if self.optimizer_disc is not None:
+            self.engine.set_lr(L.ROLE_CRITIC, self.optimizer_disc.param_groups[0]["lr"])
+            self.engine.set_lr(L.ROLE_GENERATOR, self.optimizer_gen.param_groups[0]["lr"])
+
+    # ---- data-parallel plumbing ---------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group)
+        return 1
+
+    def _allreduce(self, role):
+        import torch.distributed as dist
+        dist.all_reduce(self.engine.flat[role]["g"], op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def _prep(self, gene_expression, text_token, text_token_padding, patches, padding_mask):
+        dev = self.device
+        x = gene_expression.to(torch.float32).to(dev).contiguous()
+        text = text_token.to(dev, torch.float32).contiguous()
+        tpad = text_token_padding.to(dev)
+        pat = patches.to(dev, torch.float32).contiguous()
+        ppad = padding_mask.to(dev)
+        self._ensure_capacity(x.shape[0], pat.shape[1], text.shape[1])
+        return x, text, tpad, pat, ppad
+
+    # ---- trainer (R:376-477) ------------------------------------------------------------------------------------
+    def train_disc(self, real_data, z, text_token, text_token_padding, patches, padding_mask):
+        x, text, tpad, pat, ppad = self._prep(real_data, text_token, text_token_padding, patches, padding_mask)
+        self._sync_lr()
+        alpha = torch.rand(x.shape[0], 1, device=self.device)             # R:354 (same draw, same place)
+        eng = self.engine
+        eng.critic_backward(x, z.to(self.device, torch.float32).contiguous(), alpha, pat, ppad, text, tpad)
+        w = self._world()
+        if w > 1:
+            self._allreduce(L.ROLE_CRITIC)
+        eng.critic_apply(1.0 / w)
+        self._publish_critic_losses()
+
+    def train_gen(self, z, text_token, text_token_padding, patches, padding_mask):
+        dev = self.device
+        text = text_token.to(dev, torch.float32).contiguous()
+        pat = patches.to(dev, torch.float32).contiguous()
+        self._ensure_capacity(z.shape[0], pat.shape[1], text.shape[1])
+        self._sync_lr()
+        eng = self.engine
+        eng.generator_backward(z.to(dev, torch.float32).contiguous(), pat, padding_mask.to(dev), text, text_token_padding.to(dev))
+        w = self._world()
+        if w > 1:
+            self._allreduce(L.ROLE_GENERATOR)
+        eng.generator_apply(1.0 / w)
+        self._publish_gen_loss()
+
+    def _publish_critic_losses(self):
+        l = self.engine.losses.tolist()                                     # one host sync (reference: three, R:421-423)
+        d_real, d_fake, gp = l[L.LOSS_D_REAL], l[L.LOSS_D_FAKE], l[L.LOSS_GP]
+        self.disc_loss = torch.tensor(d_real + d_fake + self.gp_weight * gp, device=self.device)
+        self.d_batch_loss = np.array([d_real + d_fake, d_real, d_fake])
+        self.gp_value = gp
+
+    def _publish_gen_loss(self):
+        g = float(self.engine.losses[L.LOSS_G])
+        self.gen_loss = torch.tensor(g, device=self.device)
+        self.g_batch_loss = np.array([g])
+
+    def train(self, gene_expression, text_token, text_token_padding, patches, padding_mask):
+        x, text, tpad, pat, ppad = self._prep(gene_expression, text_token, text_token_padding, patches, padding_mask)
+        self._sync_lr()
+        B, n = x.shape[0], self.n_critic
+        dev = self.device
+        # same torch RNG draws, in the same order, as the reference loop (z, alpha) x n_critic, then z (R:472-476)
+        z_all = torch.empty(n + 1, B, self.latent_dims, device=dev)
+        alpha_all = torch.empty(n, B, device=dev)
+        for k in range(n):
+            z_all[k] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev)
+            alpha_all[k] = torch.rand(B, 1, device=dev).view(B)
+        z_all[n] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev)
+        self.train_with_noise(x, text, tpad, pat, ppad, z_all, alpha_all)
+
+    def train_with_noise(self, x, text, tpad, pat, ppad, z_all, alpha_all, sync_losses=True):
+        """One train() with explicit z [n_critic+1,B,L] / alpha [n_critic,B] (parity and DP tests)."""
+        eng = self.engine
+        w = self._world()
+        n = alpha_all.shape[0]
+        if w == 1:
+            eng.train_step(x, pat, ppad, text, tpad, z_all, alpha_all)     # whole step enqueued by ONE C call
+        else:
+            for k in range(n):
+                eng.critic_backward(x, z_all[k], alpha_all[k], pat, ppad, text, tpad)
+                self._allreduce(L.ROLE_CRITIC)
+                eng.critic_apply(1.0 / w)
+            eng.generator_backward(z_all[n], pat, ppad, text, tpad)
+            self._allreduce(L.ROLE_GENERATOR)
+            eng.generator_apply(1.0 / w)
+        if sync_losses:
+            self._publish_critic_losses()
+            self._publish_gen_loss()
+
+    # ---- inference (R:601-608) -------------------------------------------------------------------------------------
+    def generate_samples(self, gene_expression, text_embedding, text_padding, patches, padding_mask):
+        with torch.no_grad():
+            self.gen.eval()
+            x_real = gene_expression.clone().to(torch.float32)
+            z = torch.normal(0, 1, size=(x_real.shape[0], self.latent_dims), device=self.device)
+            x_gen = self.gen(z, patches, padding_mask, text_embedding, text_padding)
+        return x_real, x_gen
+
+    # ---- epoch loop (R:619-711): training, LR halving, loss bookkeeping, checkpoints ----------------------------
+    def fit(self, train_data, val_data=None, test_data=None, epochs=1, val=False):
+        """Training part of the reference fit(): evaluation/plots (R:712-894) are out of scope."""
+        self.build_WGAN_GP()
+        if self.isTrain:
+            self.init_train()
+        for epoch in range(epochs):
+            if epoch % 100 == 0 and epoch != 0:                                  # R:649-657
+                for opt in (self.optimizer_disc, self.optimizer_gen):
+                    for group in opt.param_groups:
+                        group["lr"] = group["lr"] * 0.50
+            self.epoch = epoch
+            d_loss_all, d_batch_loss, g_batch_loss, nb = 0.0, None, None, 0
+            for i, data in enumerate(train_data):
+                self.train(data[2], data[0], data[1], data[3], data[4])             # R:667-673
+                d_loss_all += self.disc_loss.item()
+                d_batch_loss = self.d_batch_loss if d_batch_loss is None else d_batch_loss + self.d_batch_loss
+                g_batch_loss = self.g_batch_loss if g_batch_loss is None else g_batch_loss + self.g_batch_loss
+                nb += 1
+                if (i + 1) % self.freq_print == 0:
+                    print("[Epoch %d/%d] [Batch %d/%d] [D loss : %f] [G loss : %f]"
+                          % (epoch + 1, epochs, i + 1, len(train_data), self.disc_loss.item(), self.gen_loss.item()))
+            d_batch_loss = d_batch_loss / max(nb, 1)
+            self.loss_dict["d loss"].append(d_batch_loss[0])
+            self.loss_dict["d real loss"].append(d_batch_loss[1])
+            self.loss_dict["d fake loss"].append(d_batch_loss[2])
+            self.loss_dict["g loss"].append(g_batch_loss[0])
+            print("Averge D Loss:", d_loss_all / max(nb, 1))
+            if self.result_dire and (epoch + 1) % self.freq_compute_test == 0:       # R:710-711
+                torch.save(self.gen.state_dict(), os.path.join(self.result_dire, f"generator_epoch_{epoch + 1}.pt"))
+                torch.save(self.disc.state_dict(), os.path.join(self.result_dire, f"discriminator_epoch_{epoch + 1}.pt"))
+        if self.result_dire:                                                           # R:743-744
+            torch.save(self.gen.state_dict(), os.path.join(self.result_dire, "generator_last_epoch.pt"))
+            torch.save(self.disc.state_dict(), os.path.join(self.result_dire, "discriminator_last_epoch.pt"))
+        return self.loss_dict

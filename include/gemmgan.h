@@ -1,0 +1,156 @@
+/* gemmgan.h - C ABI of the MI355X-native WGAN-GP engine (libgemmgan.so).
+ *
+ * Drop-in boundary for the hot path of francescapia/-GeMM-GAN,
+ * /root/reference/src/conditional_gan_cross_attention_with_film.py (cited as R: below).
+ * The reference has no FFI of its own: its boundary is the Python object API
+ * (generator.forward R:128, discriminator.forward R:197, WGAN_GP.train_disc R:376,
+ * WGAN_GP.train_gen R:425, WGAN_GP.train R:463, WGAN_GP.generate_samples R:601).  Each entry
+ * point below names the reference function it replaces; gemm_gan_amd/model.py binds them with
+ * ctypes behind the reference's own class and method names.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*;
+ *   - every function returns 0 on success, non-zero on failure; gg_last_error() gives the text;
+ *     nothing aborts the process;
+ *   - all float tensors are fp32, row-major, contiguous, batch first; masks are bytes
+ *     (non-zero = padded / ignored), exactly the reference's torch.bool convention (R:143);
+ *   - the caller owns every buffer (parameters, gradients, optimiser state, workspace are
+ *     allocated by the host framework and bound once); inputs are borrowed and never written.
+ *   - one host thread drives one engine; kernels are enqueued on the given stream and the
+ *     functions return without synchronising.
+ */
+#ifndef GEMMGAN_H
+#define GEMMGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_ROLE_GENERATOR 0
+#define GG_ROLE_CRITIC 1
+
+#define GG_OPT_RMSPROP 0 /* torch.optim.RMSprop(lr)                       R:324 */
+#define GG_OPT_ADAM 1    /* torch.optim.Adam(lr, betas=(.9,.99))          R:327 */
+#define GG_OPT_ADAMW 2   /* torch.optim.AdamW(lr, betas=(.9,.99), wd=.01) R:330 */
+
+/* loss slots written by the iteration entry points (device float[GG_N_LOSSES]) */
+#define GG_LOSS_D_REAL 0 /* mean(-D(x))        R:43  */
+#define GG_LOSS_D_FAKE 1 /* mean(D(G(z)))      R:44  */
+#define GG_LOSS_GP 2     /* mean((|grad|-1)^2) R:374 */
+#define GG_LOSS_G 3      /* mean(-D(G(z)))     R:36  */
+#define GG_N_LOSSES 8
+
+typedef struct gg_config {
+    /* model shape: WGAN_GP.__init__ kwargs R:258-271, generator/discriminator ctors R:99, R:169 */
+    int32_t n_genes;        /* input_dims / vector_dims (G)                           */
+    int32_t latent_dims;    /* L                                                      */
+    int32_t embedding_dims; /* E (d_model); FFN width is 2E (R:115)                   */
+    int32_t hidden_dims;    /* H: generator_dims=[H,H,G], discriminator_dims=[H,H,1]  */
+    int32_t text_dims;      /* text_embedding_dims (Dt)                               */
+    int32_t patch_dims;     /* patches_embedding_dims (Dp)                            */
+    int32_t n_heads;        /* 4 (R:115, R:121)                                       */
+    int32_t n_layers;       /* 2 (R:119)                                              */
+    float negative_slope;   /* LeakyReLU slope of the MLP blocks (R:56)               */
+    float dropout;          /* encoder-layer dropout in train mode (R:116: 0.1)       */
+    /* trainer */
+    float lr_d, lr_g;       /* R:265 */
+    int32_t optimizer;      /* GG_OPT_* (R:320-331) */
+    float gp_weight;        /* R:266 */
+    float clip_d, clip_g;   /* clip_grad_norm_ max_norm, <=0 disables (R:414: 10, R:457: 2) */
+    /* capacity the workspace is sized for */
+    int32_t max_batch;      /* B */
+    int32_t max_patches;    /* P (encoder sequence is P+1 with the CLS token, R:142) */
+    int32_t max_text_tokens;/* T */
+    uint64_t seed;          /* dropout stream seed (z / alpha are supplied by the caller) */
+} gg_config;
+
+typedef struct gg_engine gg_engine;
+
+/* conditioning inputs of one minibatch (R:463 arguments after gene_expression) */
+typedef struct gg_cond {
+    const float* patches;     /* [B,P,Dp] */
+    const uint8_t* patch_pad; /* [B,P]  non-zero = padded */
+    const float* text;        /* [B,T,Dt], token 0 = text CLS */
+    const uint8_t* text_pad;  /* [B,T] */
+    int32_t B, P, T;
+} gg_cond;
+
+const char* gg_last_error(void);
+const char* gg_version(void);
+
+/* ---- construction: WGAN_GP.__init__ + build_WGAN_GP (R:258, R:334) ------------------------- */
+int gg_create(const gg_config* cfg, gg_engine** out);
+void gg_destroy(gg_engine* e);
+
+/* ---- parameter layout: the live state_dict entries of each network ------- */
+int gg_param_count(const gg_engine* e, int role);
+const char* gg_param_name(const gg_engine* e, int role, int index);
+/* offset (in floats) into the flat parameter buffer, element count, and shape (ndim <= 3) */
+int gg_param_info(const gg_engine* e, int role, int index, int64_t* offset, int64_t* numel,
+                  int32_t* ndim, int32_t shape[3]);
+int64_t gg_flat_numel(const gg_engine* e, int role); /* floats in the flat buffer (16-B aligned slots) */
+
+/* ---- binding of caller-owned device memory ------------------------------------------------------- */
+/* params / grads / state1 / state2: flat fp32 buffers of gg_flat_numel floats.  state = optimiser
+ * state (RMSprop square_avg | Adam exp_avg, exp_avg_sq); must be zero-initialised by the caller. */
+int gg_bind_net(gg_engine* e, int role, float* params, float* grads, float* state1, float* state2);
+size_t gg_workspace_bytes(const gg_engine* e);
+int gg_bind_workspace(gg_engine* e, void* workspace, size_t bytes);
+
+/* ---- forward passes: generator.forward (R:128) / discriminator.forward (R:197) ---------------- */
+/* v = z [B,L] (generator) or gene_expression [B,G] (critic); out = [B,G] or [B,1].
+ * train != 0 applies dropout exactly where nn.TransformerEncoderLayer does in train() mode. */
+int gg_forward(gg_engine* e, int role, const float* v, const gg_cond* c, float* out, int train, void* stream);
+
+/* ---- one critic update, split at the gradient all-reduce: WGAN_GP.train_disc (R:376-423) --------
+ * backward: G(z) (frozen), D(fake), D(real), D_loss, gradient penalty incl. double backward
+ * (R:351-374), all critic gradients -> bound grads buffer (overwritten).  losses: device float[8].
+ * apply:    clip_grad_norm_(10) + optimiser step (R:414-415).  grad_scale multiplies every gradient
+ *           first (1/world_size after a SUM all-reduce of the flat gradient buffer). */
+int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const float* alpha,
+                       const gg_cond* c, float* losses, void* stream);
+int gg_critic_apply(gg_engine* e, float grad_scale, void* stream);
+
+/* ---- one generator update: WGAN_GP.train_gen (R:425-461) ------------------------------------------ */
+int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* c, float* losses, void* stream);
+int gg_generator_apply(gg_engine* e, float grad_scale, void* stream);
+
+/* ---- whole step on one GPU: WGAN_GP.train (R:463-477) -----------------------------------------------
+ * z_all [n_critic+1, B, L], alpha_all [n_critic, B]; losses hold the LAST critic iteration's
+ * D_real / D_fake / GP (what d_batch_loss reports, R:421) and the generator loss. */
+int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* c, const float* z_all,
+                  const float* alpha_all, int n_critic, float* losses, void* stream);
+
+/* ---- knobs mirrored from the reference trainer ------------------------------------------------------ */
+int gg_set_lr(gg_engine* e, int role, float lr);     /* optimizer.param_groups[i]['lr'] (R:651-657) */
+int gg_set_dropout(gg_engine* e, float p);            /* parity runs use 0 */
+int gg_set_seed(gg_engine* e, uint64_t seed);
+int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
+int gg_get_optimizer_step(const gg_engine* e, int role); /* Adam/AdamW bias-correction step count   */
+int gg_set_optimizer_step(gg_engine* e, int role, int step);
+
+/* ---- test hooks: individual kernels through the same ABI (tests/ only) ---------------------------- */
+int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                 int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
+                 float slope, int accumulate, void* stream);
+/* device pointer + element count of a named internal activation buffer of the LAST call, e.g.
+ * "D.x0", "D.L0.P", "G.c", "X2", "gp_grad" (list in engine.hip); lets tests localise a mismatch. */
+int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel);
+/* ---- live per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ---------
+ * gg_profile_enable(e, 1) brackets every subsequent GEMM launch with an event pair taken from a pool;
+ * gg_profile_collect synchronises the events and aggregates per kernel class (= kernel symbol:
+ * "gemm_f32<A-layout,B-layout>") launches, total milliseconds, algorithmic FLOPs (2*M*N*K*batch) and
+ * algorithmic bytes ((M*K + K*N + M*N)*4*batch).  gg_profile_read returns row i of the aggregate. */
+int gg_profile_enable(gg_engine* e, int on);
+int gg_profile_collect(gg_engine* e);            /* returns number of classes, <0 on error */
+int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* launches, double* ms,
+                    double* flops, double* bytes);
+/* counters of the last gg_train_step / iteration: kernels launched */
+int64_t gg_launch_count(const gg_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMMGAN_H */

@@ -1,0 +1,137 @@
+"""HIP engine vs oracle #1 (torch CPU autograd) on seeded inputs at sizes the oracle finishes in
+seconds, incl. the hot-path tile shapes (E=256, dh=64, S=65), ragged masks, T>1; plus
+size-independent properties at BASELINE.json's full cfg3 size."""
+import numpy as np
+import pytest
+import torch
+
+from gemm_gan_amd import _lib as L
+from gpu_util import Checker, dev, engine_from_cfg, load_oracle_state
+from oracle.torch_oracle import PathConfig, Trainer, set_dropout, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+CASES = {
+    "mid_T5_ragged": dict(cfg=PathConfig(n_genes=300, latent_dims=48, embedding_dims=64, hidden_dims=96, text_dims=40,
+                                          patch_dims=72, dropout=0.0), B=12, P=37, T=5),
+    "hot_tiles_E256": dict(cfg=PathConfig(n_genes=1000, latent_dims=256, embedding_dims=256, hidden_dims=256,
+                                           text_dims=512, patch_dims=1024, dropout=0.0), B=8, P=64, T=1),
+    "leaky_T300": dict(cfg=PathConfig(n_genes=130, latent_dims=32, embedding_dims=32, hidden_dims=64, text_dims=24,
+                                       patch_dims=16, dropout=0.0, negative_slope=0.2), B=6, P=9, T=300),
+}
+
+
+def setup(case, seed=11):
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(seed)
+    tr = Trainer(cfg)
+    set_dropout(tr.gen, 0.0)
+    set_dropout(tr.disc, 0.0)
+    batch = synthetic_batch(cfg, B, P, T, seed=seed + 1, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+    load_oracle_state(eng, tr)
+    return cfg, tr, eng, batch
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_critic_and_generator_iteration_vs_autograd(case):
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    B = x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    ck = Checker(f"oracle critic/gen iteration {case}", TOL)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    l = eng.losses.tolist()
+    ck.check("d_real,d_fake,gp", np.array(l[:3]), np.array([r["d_real"].item(), r["d_fake"].item(), r["gp"].item()]))
+    ck.check("x_fake", eng.debug_buffer("X2").view(2 * B, -1)[:B], r["x_fake"])
+    ck.check("grad_x_hat", eng.debug_buffer("gp_grad").view(B, -1), r["grad_x_hat"].detach())
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    for n, ref in r["grads"].items():
+        if ref is not None:
+            ck.check("dD " + n, grads[n], ref)
+    rg = tr.generator_iteration(z, cond, apply=False)
+    eng.generator_backward(zg, pg, ppg, tg, tpg)
+    ck.check("g_loss", np.array([eng.losses.tolist()[3]]), np.array([rg["g_loss"].item()]))
+    grads = eng.state(L.ROLE_GENERATOR, "g")
+    for n, ref in rg["grads"].items():
+        if ref is not None:
+            ck.check("dG " + n, grads[n], ref)
+    ck.done()
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE cfg3 (B=256, G=5000, P=256, Dp=1024, T=1, Dt=512): size-independent properties.
+    (1) critic score is independent of the batch composition (row b of a half batch == row b of the
+    full batch); (2) data-parallel identity: the gradient of the full batch equals the mean of the two
+    half-batch gradients; (3) everything finite; (4) GP gradient norm matches the row norm of grad_x_hat."""
+    cfg = PathConfig(dropout=0.0)
+    B, P, T = 256, 256, 1
+    torch.manual_seed(3)
+    tr = Trainer(cfg)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+    load_oracle_state(eng, tr)
+    x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=9, pad_patches=True))
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    ck = Checker("full-size cfg3 properties", 1e-3)
+    full = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
+    h = B // 2
+    half = eng.forward(L.ROLE_CRITIC, x[h:].contiguous(), patches[h:].contiguous(), patch_pad[h:].contiguous(),
+                       text[h:].contiguous(), text_pad[h:].contiguous(), train=False)
+    assert torch.isfinite(full).all()
+    ck.check("critic rows independent of batch", half, full[h:], tol=1e-5)
+    eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+    gfull = eng.flat[L.ROLE_CRITIC]["g"].clone()
+    nrm = eng.debug_buffer("gp_grad").view(B, -1).norm(dim=1)
+    ck.check("|grad_x_hat| vs gp_nrm2", nrm ** 2, eng.debug_buffer("gp_nrm2"), tol=1e-5)
+    assert torch.isfinite(gfull).all()
+    acc = torch.zeros_like(gfull)
+    for s in (slice(0, h), slice(h, B)):
+        eng.critic_backward(x[s].contiguous(), z[s].contiguous(), alpha[s].contiguous(), patches[s].contiguous(),
+                            patch_pad[s].contiguous(), text[s].contiguous(), text_pad[s].contiguous())
+        acc += eng.flat[L.ROLE_CRITIC]["g"]
+    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=2e-4)
+    ck.done()
+
+
+def test_dropout_statistics_and_replicas():
+    """p=0.1: attention-probability dropout zeroes ~10 % of the unmasked probabilities, survivors are
+    scaled by 1/(1-p); the three critic passes of one iteration draw independent masks; backward
+    regenerates the same masks (finite-difference free check: gradients stay finite and the loss
+    of a second identical call with the same seed reproduces)."""
+    cfg = PathConfig(n_genes=200, latent_dims=32, embedding_dims=64, hidden_dims=64, text_dims=24, patch_dims=48, dropout=0.1)
+    B, P, T = 16, 31, 2
+    torch.manual_seed(2)
+    tr = Trainer(cfg)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=77)
+    load_oracle_state(eng, tr)
+    x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=4))
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+    S = P + 1
+    # backward re-materialises the dropped probabilities layer by layer, ending with layer 0, for the
+    # two replicas that carry gradient: the first 2B slabs of sPd are layer 0's regenerated mask
+    Pm = eng.debug_buffer("D.L0.P").view(3 * B, 4, S, S)[:2 * B]
+    Pd = eng.debug_buffer("sPd").view(3 * B, 4, S, S)[:2 * B]
+    zero_frac = float(((Pd == 0) & (Pm > 0)).float().sum() / (Pm > 0).float().sum())
+    assert 0.09 < zero_frac < 0.11, zero_frac
+    kept = Pd != 0
+    assert torch.allclose(Pd[kept], Pm[kept] / 0.9, rtol=1e-5)
+    c = eng.debug_buffer("D.c").view(3, B, -1)
+    assert (c[0] - c[1]).abs().max() > 1e-4 and (c[1] - c[2]).abs().max() > 1e-4   # independent draws
+    l1 = eng.losses.clone()
+    g1 = eng.flat[L.ROLE_CRITIC]["g"].clone()
+    assert torch.isfinite(g1).all()
+    eng.set_seed(77)
+    eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+    assert torch.allclose(eng.losses, l1, rtol=1e-5, atol=1e-6)
+    assert (eng.flat[L.ROLE_CRITIC]["g"] - g1).abs().max() <= 1e-4 * g1.abs().max()
