@@ -330,6 +330,7 @@ class WGAN_GP:
     def train_with_noise(self, x, text, tpad, pat, ppad, z_all, alpha_all, sync_losses=True):
         """One train() with explicit z [n_critic+1,B,L] / alpha [n_critic,B] (parity and DP tests)."""
         eng = self.engine
+        self._sync_lr()
         w = self._world()
         n = alpha_all.shape[0]
         if w == 1:
