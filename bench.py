@@ -46,34 +46,55 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
-    bounded sample: the same workload at a smaller minibatch, 1 warm-up + 2 timed train() steps."""
-    from oracle.torch_oracle import PathConfig, Trainer, synthetic_batch
-    cores = os.cpu_count() or 1
+def host_cores():
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask, capped at 16
+    (one GPU's share of a box; oversubscribing torch threads beyond the quota stalls for minutes)."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(args):
+    """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
+    bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 3 timed train() steps."""
+    from oracle.torch_oracle import PathConfig, Trainer, synthetic_batch
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = PathConfig(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
     Bc = args.cpu_batch
     torch.manual_seed(42)
     tr = Trainer(cfg)
     x, text, text_pad, patches, patch_pad = synthetic_batch(cfg, Bc, args.patches, args.tokens, seed=42)
+
     def step():
         zs = [torch.randn(Bc, cfg.latent_dims) for _ in range(cfg.n_critic + 1)]
         al = [torch.rand(Bc, 1) for _ in range(cfg.n_critic)]
         tr.train_step(x, text, text_pad, patches, patch_pad, zs, al)
-    step()
     t0 = time.perf_counter()
-    n = 2
+    step()
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(20.0 / max(warm, 1e-3))))
+    log(f"cpu baseline: warm-up step {warm:.1f} s on {cores} threads, timing {n} step(s)")
+    t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
     return dict(value=round(Bc * n / dt, 3), unit="samples/s", cores=cores, kind="port",
-                sample=f"oracle/torch_oracle.py (stock torch CPU modules, fp32), same workload at minibatch {Bc}: "
-                       f"1 warm-up + {n} timed train() steps, {dt:.1f} s")
+                sample=f"oracle/torch_oracle.py (stock torch CPU modules, fp32, dropout {args.dropout}), same workload at "
+                       f"minibatch {Bc}: 1 warm-up + {n} timed train() steps, {dt:.1f} s")
 
 
 def main():
@@ -81,6 +102,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        try:                                  # host-only, before the GPU is touched
+            cpu = cpu_baseline(args)
+        except Exception as ex:  # pragma: no cover
+            cpu = {"error": repr(ex)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -111,8 +138,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    log(f"engine ready: workspace {w.engine.workspace_bytes / 2**30:.1f} GiB; warm-up {args.warmup} step(s)")
+    for i in range(args.warmup):
+        t1 = time.perf_counter()
         w.train(x, text, text_pad, patches, patch_pad)
+        torch.cuda.synchronize(dev)
+        log(f"warm-up step {i}: {(time.perf_counter() - t1) * 1e3:.1f} ms")
     prof = (not args.no_profile) and rank == 0
     sync()
     if prof:
@@ -161,11 +192,8 @@ def main():
                                "all_gemm_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),
                                                      "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                                                      "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows]}
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args)
-            except Exception as ex:  # pragma: no cover
-                out["cpu_baseline"] = {"error": repr(ex)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

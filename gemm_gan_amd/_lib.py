@@ -17,6 +17,7 @@ ROLE_GENERATOR, ROLE_CRITIC = 0, 1
 OPT_KINDS = {"rms_prop": 0, "adam": 1, "adamw": 2}
 LOSS_D_REAL, LOSS_D_FAKE, LOSS_GP, LOSS_G, N_LOSSES = 0, 1, 2, 3, 8
 LAY_KC, LAY_KS = 0, 1
+PRECISIONS = {"f32": 0, "bf16": 1}
 
 
 class GGConfig(C.Structure):
@@ -26,7 +27,7 @@ class GGConfig(C.Structure):
                 ("dropout", C.c_float), ("lr_d", C.c_float), ("lr_g", C.c_float), ("optimizer", C.c_int32),
                 ("gp_weight", C.c_float), ("clip_d", C.c_float), ("clip_g", C.c_float),
                 ("max_batch", C.c_int32), ("max_patches", C.c_int32), ("max_text_tokens", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("precision", C.c_int32)]
 
 
 class GGCond(C.Structure):
@@ -57,12 +58,16 @@ SYMBOLS = {
     "gg_set_lr": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "gg_set_dropout": (C.c_int, [C.c_void_p, C.c_float]),
     "gg_set_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "gg_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_reset_optimizer_steps": (C.c_int, [C.c_void_p]),
     "gg_get_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gg_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
                                C.c_int, C.c_void_p]),
+    "gg_test_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                    C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
+                                    C.c_int, C.c_void_p]),
     "gg_launch_count": (C.c_int64, [C.c_void_p]),
     "gg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_profile_collect": (C.c_int, [C.c_void_p]),

@@ -99,6 +99,7 @@ struct gg_engine {
     int maxB, maxP, maxT, maxS, maxR;
     Net net[2];
     float dropout = 0.f;
+    int precision = GG_PREC_F32;
     uint64_t seed = 0;
     uint32_t call_counter = 0;
     int64_t launches = 0;
@@ -274,7 +275,8 @@ inline long tiles_of(long M, long N) { return ((M + 127) / 128) * ((N + 127) / 1
 int run_gemm(Ctx& c, const GemmP& p) {
     gg_engine* e = c.e;
     e->launches++;
-    if (!e->prof_on) return gemm_f32(p, c.st);
+    const bool bf16 = e->precision == GG_PREC_BF16;
+    if (!e->prof_on) return bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st);
     if (e->prof_next + 2 > e->prof_pool.size()) {
         for (int i = 0; i < 4096; ++i) {
             hipEvent_t ev;
@@ -283,14 +285,14 @@ int run_gemm(Ctx& c, const GemmP& p) {
         }
     }
     gg_engine::ProfRec r;
-    r.cls = p.layA * 2 + p.layB;
+    r.cls = p.layA * 2 + p.layB + (bf16 ? 4 : 0);
     const double b = (double)p.batch;
     r.flops = 2.0 * p.M * p.N * (double)p.K * b;
     r.bytes = 4.0 * b * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
     r.e0 = e->prof_pool[e->prof_next++];
     r.e1 = e->prof_pool[e->prof_next++];
     GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
-    int rc = gemm_f32(p, c.st);
+    int rc = bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st);
     GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
     e->prof_recs.push_back(r);
     return rc;
@@ -588,7 +590,7 @@ int head_finish(Ctx& c, Net& n, const float* cvec, float* a1, float* a2, float* 
 // [rows, V], cvec [rows, E].  If param_grads: accumulate the six parameter gradients.  Outputs:
 // dcond [rows,E] (may be null), dv [rows,V] (may be null).
 int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const float* cvec, const float* a1, const float* a2,
-                  int rows, bool param_grads, float* dcond, float* dv) {
+                  int rows, bool param_grads, float* dcond, float* dv, bool out_bias_grad = true) {
     gg_engine* e = c.e;
     const int E = e->E, H = e->H, V = n.V, OUT = n.OUT;
     const float* w = n.w;
@@ -598,7 +600,7 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
     float* dh1 = e->dB;
     if (param_grads) {
         GG_TRY(lin_bwd_weight(c, dout, OUT, a2, H, g + n.w3, H, rows, OUT, H));
-        KL(k_colsum(dout, rows, OUT, OUT, g + n.b3, c.st));
+        if (out_bias_grad) KL(k_colsum(dout, rows, OUT, OUT, g + n.b3, c.st));
     }
     GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));
     KL(k_act_bwd(dh2, a2, (long)rows * H, slope, 1.f, c.st));
@@ -673,7 +675,10 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     GG_TRY(head_finish(c, D, e->c3, e->headD.a1, e->headD.a2, e->headD.out, 1, 3 * B, 2 * B));
     KL(k_critic_loss_seed(e->headD.out, e->dseed, losses, B, c.st));
     // D_loss backward through the head for the 2B fake/real rows
-    GG_TRY(head_backward(c, D, e->dseed, e->X2, e->c3, e->headD.a1, e->headD.a2, 2 * B, true, e->dc, nullptr));
+    // d(D_loss)/d(final bias) = sum(+1/B) + sum(-1/B) is identically zero (the reference's two symmetric
+    // sums cancel exactly, R:43-45); summing the 2B seeds in one pass would leave ~1e-8 of rounding that
+    // RMSprop/Adam normalise into a +-O(lr) drift of the critic's output offset, so it is not computed.
+    GG_TRY(head_backward(c, D, e->dseed, e->X2, e->c3, e->headD.a1, e->headD.a2, 2 * B, true, e->dc, nullptr, false));
     // ---- gradient penalty, closed form on the interpolate rows -------------------------
     const float* a1h = e->headD.a1 + 2L * B * H;
     const float* a2h = e->headD.a2 + 2L * B * H;
@@ -749,6 +754,8 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
     e->dropout = cfg->dropout;
     e->seed = cfg->seed;
+    GG_REQUIRE(cfg->precision == GG_PREC_F32 || cfg->precision == GG_PREC_BF16, "bad precision");
+    e->precision = cfg->precision;
     build_net(e, GG_ROLE_GENERATOR);
     build_net(e, GG_ROLE_CRITIC);
     e->net[GG_ROLE_GENERATOR].lr = cfg->lr_g;
@@ -860,6 +867,11 @@ int gg_set_dropout(gg_engine* e, float p) {
     e->dropout = p;
     return 0;
 }
+int gg_set_precision(gg_engine* e, int precision) {
+    GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16), "bad precision");
+    e->precision = precision;
+    return 0;
+}
 int gg_set_seed(gg_engine* e, uint64_t seed) {
     GG_REQUIRE(e, "null argument");
     e->seed = seed;
@@ -887,9 +899,10 @@ int gg_profile_enable(gg_engine* e, int on) {
 }
 int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
-    static const char* names[4] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>"};
-    e->prof_agg.assign(4, gg_engine::ProfAgg());
-    for (int i = 0; i < 4; ++i) e->prof_agg[i].name = names[i];
+    static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
+                                   "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
+    e->prof_agg.assign(8, gg_engine::ProfAgg());
+    for (int i = 0; i < 8; ++i) e->prof_agg[i].name = names[i];
     for (auto& r : e->prof_recs) {
         if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("hipEventSynchronize failed"); return -1; }
         float ms = 0.f;
@@ -972,6 +985,17 @@ int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
     p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
     p.accumulate = accumulate;
     return gemm_f32(p, (hipStream_t)stream);
+}
+
+
+int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                      int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                      void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_bf16(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -71,6 +71,7 @@ struct GemmP {
     int c_row_group = 0;
 };
 
-int gemm_f32(const GemmP& p, hipStream_t st);
+int gemm_f32(const GemmP& p, hipStream_t st);    // exact fp32 (v_mfma_f32_32x32x2_f32)
+int gemm_bf16(const GemmP& p, hipStream_t st);   // bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)
 
 }  // namespace gg

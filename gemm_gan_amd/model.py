@@ -161,7 +161,7 @@ class WGAN_GP:
                  n_critic=5, freq_print=2, freq_compute_test=50, freq_visualize_test=100, patience=10,
                  normalization="standardize", log2=False, rpm=False, results_dire="",
                  # --- extensions (keyword-only in spirit; defaults reproduce the reference) ---
-                 dropout=0.1, seed=0, device=None, process_group=None):
+                 dropout=0.1, seed=0, device=None, process_group=None, precision="f32"):
         self.input_dims = input_dims
         self.latent_dims = latent_dims
         self.embedding_dims = embedding_dims
@@ -200,6 +200,7 @@ class WGAN_GP:
         self.dropout = dropout
         self.seed = seed
         self.process_group = process_group
+        self.precision = precision          # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA, fp32 accumulate
         self.engine: Optional[Engine] = None
         self.gen = self.disc = None
         self.optimizer_disc = self.optimizer_gen = None
@@ -226,7 +227,7 @@ class WGAN_GP:
                      hidden_dims=H, text_dims=self.text_embedding_dims, patch_dims=self.patches_embedding_dims,
                      negative_slope=self.negative_slope, dropout=self.dropout, lr_d=self.lr_d, lr_g=self.lr_g,
                      optimizer=self.optimizer, gp_weight=float(self.gp_weight), max_batch=B, max_patches=P,
-                     max_text_tokens=T, seed=self.seed, device=self.device)
+                     max_text_tokens=T, seed=self.seed, device=self.device, precision=self.precision)
         eng._owner = self
         if old is not None:          # grow: keep parameters, gradients, optimiser state and step counters
             for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):

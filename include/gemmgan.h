@@ -31,6 +31,10 @@ extern "C" {
 #define GG_ROLE_GENERATOR 0
 #define GG_ROLE_CRITIC 1
 
+/* arithmetic of the GEMM-shaped products (everything else is fp32 in both modes) */
+#define GG_PREC_F32 0  /* fp32-input MFMA: exact fp32, the parity mode (<= 1e-3 vs the reference) */
+#define GG_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate: the throughput mode               */
+
 #define GG_OPT_RMSPROP 0 /* torch.optim.RMSprop(lr)                       R:324 */
 #define GG_OPT_ADAM 1    /* torch.optim.Adam(lr, betas=(.9,.99))          R:327 */
 #define GG_OPT_ADAMW 2   /* torch.optim.AdamW(lr, betas=(.9,.99), wd=.01) R:330 */
@@ -64,6 +68,7 @@ typedef struct gg_config {
     int32_t max_patches;    /* P (encoder sequence is P+1 with the CLS token, R:142) */
     int32_t max_text_tokens;/* T */
     uint64_t seed;          /* dropout stream seed (z / alpha are supplied by the caller) */
+    int32_t precision;      /* GG_PREC_* */
 } gg_config;
 
 typedef struct gg_engine gg_engine;
@@ -127,6 +132,7 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* c, const flo
 int gg_set_lr(gg_engine* e, int role, float lr);     /* optimizer.param_groups[i]['lr'] (R:651-657) */
 int gg_set_dropout(gg_engine* e, float p);            /* parity runs use 0 */
 int gg_set_seed(gg_engine* e, uint64_t seed);
+int gg_set_precision(gg_engine* e, int precision);    /* GG_PREC_* ; may be switched between calls */
 int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
 int gg_get_optimizer_step(const gg_engine* e, int role); /* Adam/AdamW bias-correction step count   */
 int gg_set_optimizer_step(gg_engine* e, int role, int step);
@@ -135,6 +141,9 @@ int gg_set_optimizer_step(gg_engine* e, int role, int step);
 int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                  int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                  float slope, int accumulate, void* stream);
+int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                      int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
+                      float slope, int accumulate, void* stream);
 /* device pointer + element count of a named internal activation buffer of the LAST call, e.g.
  * "D.x0", "D.L0.P", "G.c", "X2", "gp_grad" (list in engine.hip); lets tests localise a mismatch. */
 int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel);

@@ -21,8 +21,10 @@ def rel(a, b):
     a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
     b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
-    den = max(float(np.abs(b).max()), 1e-30)
-    return float(np.abs(a - b).max() / den)
+    ref = float(np.abs(b).max()) if b.size else 0.0
+    if ref < 1e-12:      # reference is (numerically) exactly zero: accept fp32 rounding-level noise
+        return 0.0 if (a.size == 0 or float(np.abs(a).max()) < 1e-6) else float("inf")
+    return float(np.abs(a - b).max() / ref)
 
 
 class Checker:
@@ -43,6 +45,13 @@ class Checker:
         if not np.isfinite(e):
             flag = "   <-- FAIL (non-finite)"
         diag(f"   {name:55s} rel_err {e:.3e}{flag}")
+        if flag:
+            try:
+                ga = got.detach().cpu().numpy().reshape(-1) if isinstance(got, torch.Tensor) else np.asarray(got).reshape(-1)
+                wa = want.detach().cpu().numpy().reshape(-1) if isinstance(want, torch.Tensor) else np.asarray(want).reshape(-1)
+                diag(f"        got  {ga[:6]}\n        want {wa[:6]}")
+            except Exception:
+                pass
         if flag:
             self.bad.append((name, e))
 

@@ -135,3 +135,30 @@ def test_dropout_statistics_and_replicas():
     eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
     assert torch.allclose(eng.losses, l1, rtol=1e-5, atol=1e-6)
     assert (eng.flat[L.ROLE_CRITIC]["g"] - g1).abs().max() <= 1e-4 * g1.abs().max()
+
+
+def test_bf16_mode_tracks_fp32_oracle():
+    """Throughput mode (bf16 MFMA operands, fp32 accumulate): same step, looser tolerance.  bf16 has 8
+    significant bits (2^-9 relative rounding per operand); through two encoder layers the observed
+    error is ~1e-2 of each tensor's scale.  Tolerance 4e-2 on losses / gradients - a mapping or logic
+    bug shows up as O(1)."""
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup("hot_tiles_E256")
+    eng.set_precision("bf16")
+    B = x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    ck = Checker("bf16 mode vs fp32 oracle (hot_tiles_E256)", 4e-2)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    l = eng.losses.tolist()
+    ck.check("d_real,d_fake,gp", np.array(l[:3]), np.array([r["d_real"].item(), r["d_fake"].item(), r["gp"].item()]))
+    ck.check("x_fake", eng.debug_buffer("X2").view(2 * B, -1)[:B], r["x_fake"])
+    ck.check("grad_x_hat", eng.debug_buffer("gp_grad").view(B, -1), r["grad_x_hat"].detach())
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    for n, ref in r["grads"].items():
+        if ref is not None and not n.endswith("in_proj_bias"):
+            ck.check("dD " + n, grads[n], ref)
+    ck.done()

@@ -12,11 +12,12 @@ from gpu_util import Checker
 pytestmark = pytest.mark.gpu
 
 
-def run_gemm(A, B, M, N, K, layA, layB, splitk=1, alpha=1.0, bias=None, act=0, slope=0.0, C0=None, accumulate=0):
+def run_gemm(A, B, M, N, K, layA, layB, splitk=1, alpha=1.0, bias=None, act=0, slope=0.0, C0=None, accumulate=0,
+             kernel="gg_test_gemm"):
     lib = L.load()
     out = torch.zeros(M, N, device="cuda") if C0 is None else C0.clone()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib.gg_test_gemm(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(out.data_ptr()), M, N, K,
+    rc = getattr(lib, kernel)(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(out.data_ptr()), M, N, K,
                           A.stride(0), B.stride(0), N, layA, layB, splitk, C.c_float(alpha),
                           None if bias is None else C.c_void_p(bias.data_ptr()), act, C.c_float(slope), accumulate, st)
     assert rc == 0, lib.gg_last_error()
@@ -74,4 +75,36 @@ def test_gemm_hot_path_shapes():
                                   (512, 5000, 256, 0, 1, 1)]:
         Am, Bm, A, B = operands(M, N, K, la, lb, False)
         ck.check(f"{M}x{N}x{K} la{la} lb{lb} sk{sk}", run_gemm(A, B, M, N, K, la, lb, splitk=sk), Am.double() @ Bm.double())
+    ck.done()
+
+
+@pytest.mark.parametrize("layA", [0, 1])
+@pytest.mark.parametrize("layB", [0, 1])
+def test_gemm_bf16_layouts_exact_integer(layA, layB):
+    """bf16 MFMA twin: small integers are exact in bf16 and their sums exact in the fp32 accumulator, so
+    the fragment / transpose-staging maps are checked bit for bit."""
+    ck = Checker(f"gemm_bf16 exact integer layA={layA} layB={layB}", 0.0)
+    for (M, N, K) in [(32, 32, 16), (128, 128, 64), (200, 136, 72), (257, 64, 257), (5, 37, 69), (300, 260, 200)]:
+        Am, Bm, A, B = operands(M, N, K, layA, layB, True)
+        out = run_gemm(A, B, M, N, K, layA, layB, kernel="gg_test_gemm_bf16")
+        ck.check(f"{M}x{N}x{K}", out, (Am.double() @ Bm.double()).float())
+    ck.done()
+
+
+@pytest.mark.parametrize("layA,layB", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_bf16_random(layA, layB):
+    """Random operands: the result must equal the fp64 product of the bf16-ROUNDED operands to fp32
+    accumulation accuracy (this isolates kernel errors from the intended operand rounding)."""
+    ck = Checker(f"gemm_bf16 random/splitk/epilogue layA={layA} layB={layB}", 2e-5)
+    M, N, K = 260, 200, 1000
+    Am, Bm, A, B = operands(M, N, K, layA, layB, False)
+    ref = Am.bfloat16().double() @ Bm.bfloat16().double()
+    ck.check("plain", run_gemm(A, B, M, N, K, layA, layB, kernel="gg_test_gemm_bf16"), ref)
+    ck.check("splitk5", run_gemm(A, B, M, N, K, layA, layB, splitk=5, kernel="gg_test_gemm_bf16"), ref)
+    bias = torch.randn(N, device="cuda")
+    C0 = torch.randn(M, N, device="cuda")
+    want = 0.5 * ref + bias.double().cpu() + C0.double().cpu()
+    want = torch.where(want > 0, want, 0.1 * want)
+    ck.check("alpha+bias+accumulate+leaky", run_gemm(A, B, M, N, K, layA, layB, alpha=0.5, bias=bias, act=1, slope=0.1,
+                                                     C0=C0, accumulate=1, kernel="gg_test_gemm_bf16"), want)
     ck.done()
