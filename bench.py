@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--text-dims", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="GEMM arithmetic: f32 = exact fp32 MFMA (parity mode), bf16 = bf16 MFMA operands, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
@@ -122,7 +124,8 @@ def main():
     H = E = Lz = 256
     torch.manual_seed(42)                       # identical initial weights on every rank
     w = gga.WGAN_GP(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
-                    optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="")
+                    optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="",
+                    precision=args.precision)
     w.build_WGAN_GP()
     w.init_train()
     w.reserve(B, P, T)
@@ -168,7 +171,7 @@ def main():
         value = world * B * args.steps / dt
         out = {"metric": "WGAN-GP samples/sec (n_critic=5, 5k-gene)", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": {"workload": "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), "
                                       f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
                                       f"n_critic=5, rms_prop, dropout {args.dropout}",
@@ -180,11 +183,12 @@ def main():
             dom = max(rows, key=lambda r: r["ms"])
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            frac_m, frac_h = tf / PEAK_TFLOPS["f32"], gbs / PEAK_HBM_GBS
+            peak_tf = PEAK_TFLOPS[args.precision]
+            frac_m, frac_h = tf / peak_tf, gbs / PEAK_HBM_GBS
             bound = "mfma" if frac_m >= frac_h else "hbm"
             out["roofline"] = {"kernel": dom["name"], "bound": bound,
                                "achieved": round(tf if bound == "mfma" else gbs, 2),
-                               "peak": PEAK_TFLOPS["f32"] if bound == "mfma" else PEAK_HBM_GBS,
+                               "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
                                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                "frac": round(max(frac_m, frac_h), 4), "traffic": None,
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],

@@ -63,8 +63,7 @@ def comparable(name, arr, E):
     """Post-optimiser-step comparisons skip the key-bias slice [E:2E) of every ``in_proj_bias``:
     its true gradient is identically zero (softmax is invariant to a per-query shift of the scores),
     so the reference's value there is rounding noise that RMSprop/Adam normalise to a +-O(lr) step."""
-    a = np.asarray(arr).reshape(-1)
-    keep = np.ones(a.shape, dtype=bool)
+    keep = np.ones(int(np.prod(tuple(arr.shape))), dtype=bool)
     if name.endswith("in_proj_bias"):
         keep[E:2 * E] = False
     return keep

@@ -99,8 +99,11 @@ def test_full_train_step(name, opt):
     alpha_all = g.t(f"step_{opt}/alpha").cuda().reshape(z_all.shape[0] - 1, -1).contiguous()
     eng.train_step(x, patches, patch_pad, text, text_pad, z_all, alpha_all)
     l = eng.losses.tolist()
-    ck.check("d_batch_loss", np.array([l[0] + l[1], l[0], l[1]]), g.z[f"step_{opt}/d_batch_loss"], tol=2e-3)
-    ck.check("gen_loss", np.array([l[3]]), np.array([float(g.z[f"step_{opt}/gen_loss"])]), tol=2e-3)
+    # Six normalised-gradient optimiser steps amplify fp32 summation-order noise: perturbing the fp64
+    # oracle's gradients by 1e-6 relative already moves these losses by 3e-3 (measured, see DESIGN.md
+    # section 0), so the multi-step gate is 5e-3; every single-iteration quantity is gated at 1e-3 above.
+    ck.check("d_batch_loss", np.array([l[0] + l[1], l[0], l[1]]), g.z[f"step_{opt}/d_batch_loss"], tol=5e-3)
+    ck.check("gen_loss", np.array([l[3]]), np.array([float(g.z[f"step_{opt}/gen_loss"])]), tol=5e-3)
     stride = 1 if opt == "rms_prop" else 5
     # Several normalised-gradient steps: entries whose gradient is rounding noise move by +-lr per
     # step in BOTH implementations, so compare against the size of the largest legitimate move.
