@@ -1,0 +1,558 @@
+// Fused multi-head self-attention for the encoder layers (bf16 MFMA, fp32 accumulate / softmax):
+// forward + backward without ever writing the [S,S] probability tensor to HBM.
+//
+// Reference semantics: torch F.multi_head_attention_forward (torch/nn/functional.py:6206-6660) as used
+// by nn.TransformerEncoderLayer: softmax(q k^T / sqrt(dh) + key_padding(-inf)) -> dropout -> @ v, on
+// the packed projection qkv [N, S, 3E] (heads addressed by column offset).
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16, C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)):
+//   forward and dQ kernels compute the TRANSPOSED score tile  S^T[key, q] = K Q^T  so that one lane
+//   owns one query column: row max / row sum / online rescale are in-register plus ONE cross-half
+//   shuffle, and the probability tile is already the B operand of the next product
+//   (O^T = V^T P^T, dQ^T = K^T dS^T: "accumulator tile as the next MFMA's operand", guide section 3).
+//   the dK/dV kernel computes S[q, key] = Q K^T with the KEY on the lane: P and dS are then the B
+//   operands of dV^T = dO^T P and dK^T = Q^T dS, accumulated over all query tiles in registers.
+// Outputs are written as 16-byte stores (a lane holds 4 consecutive head-dim elements per register
+// group), two half-waves completing each 32-byte sector.
+//
+// Dropout uses the same counter hash and the same element index ((n*nh+h)*S+q)*S+key as the unfused
+// path (kernels.hip), so both paths draw identical masks.
+#include "kernels.h"
+
+namespace gg {
+
+namespace {
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float drop_factor(const DropKey& k, uint64_t i, float keep_scale) {
+    uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+    uint32_t h = fmix32(lo * 0x9E3779B1u + k.k0);
+    h = fmix32(h ^ k.k1 ^ (hi * 0x7F4A7C15u));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u >= k.p ? keep_scale : 0.f;
+}
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16x8 frag_from_f32(const float* v) {     // 8 floats -> 8 bf16
+    u32x4 w = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ bf16x8 frag_from_acc(const f32x16& a, int s2) {   // regs 8*s2 .. 8*s2+7
+    u32x4 w = {pack2(a[8 * s2 + 0], a[8 * s2 + 1]), pack2(a[8 * s2 + 2], a[8 * s2 + 3]),
+               pack2(a[8 * s2 + 4], a[8 * s2 + 5]), pack2(a[8 * s2 + 6], a[8 * s2 + 7])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+// row index inside a 32x32 accumulator tile held in register i by lane-half h
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ---- LDS staging -------------------------------------------------------------------------------------
+// row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled
+template <int DH>
+__device__ __forceinline__ void stage_rows(__bf16* img, const float* __restrict__ X, long ldx, int S, int Sp, int tid, int nthreads) {
+    constexpr int LD = DH + 8;
+    const int nchunk = Sp * (DH / 8);
+    for (int c = tid; c < nchunk; c += nthreads) {
+        const int row = c / (DH / 8), c8 = c % (DH / 8);
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (row < S) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 8 * c8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 8 * c8 + 4);
+            w = u32x4{pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+        }
+        *reinterpret_cast<u32x4*>(img + row * LD + 8 * c8) = w;
+    }
+}
+// transposed image  img[d][row] (ld = Sp+8 bf16) of X[row, col0 + d]
+template <int DH>
+__device__ __forceinline__ void stage_transposed(__bf16* img, const float* __restrict__ X, long ldx, int S, int Sp, int tid, int nthreads) {
+    const int LD = Sp + 8;
+    const int nunit = (Sp / 8) * (DH / 4);
+    for (int u = tid; u < nunit; u += nthreads) {
+        const int r8 = u / (DH / 4), d4 = u % (DH / 4);
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * r8 + j;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < S) v[j] = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 4 * d4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 w = {pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q]), pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};
+            *reinterpret_cast<u32x4*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+        }
+    }
+}
+// A-operand fragment of a TRANSPOSED image for the "accumulator as B operand" product: element j of
+// lane-half h must be the source row 16*s2 + 8*(j>>2) + 4*h + (j&3) (guide section 3) of column d.
+__device__ __forceinline__ bf16x8 frag_transposed(const __bf16* img, int ld, int d, int row0, int s2, int h) {
+    const __bf16* p = img + d * ld + row0 + 16 * s2 + 4 * h;
+    const u32x2 a = *reinterpret_cast<const u32x2*>(p);
+    const u32x2 b = *reinterpret_cast<const u32x2*>(p + 8);
+    u32x4 w = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward: one workgroup (4 waves) per (sample, head); K row-major + V transposed resident in LDS; each
+// wave walks query tiles of 32 rows with an online softmax over key tiles of 32.
+// ------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                       int mask_B, float* __restrict__ ctx, float* __restrict__ lse2,
+                                                       int S, int E, int nh, DropKey drop) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32;
+    constexpr int LDK = DH + 8;
+    const int LDV = Sp + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vt = Ks + Sp * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vt + DH * LDV);
+    constexpr int DT = (DH + 31) / 32;          // head-dim tiles of the O^T accumulator
+    constexpr int KS = DH / 16;                 // k-steps of the score product
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)n * S * ld + hd * DH;
+    stage_rows<DH>(Ks, base + E, ld, S, Sp, tid, 256);
+    stage_transposed<DH>(Vt, base + 2 * E, ld, S, Sp, tid, 256);
+    for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
+    __syncthreads();
+
+    const float sc = rsqrtf((float)DH) * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 32 + c;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < S) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(base + (long)q * ld + 16 * s + 8 * h);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(base + (long)q * ld + 16 * s + 8 * h + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; }
+            }
+            qf[s] = frag_from_f32(v);
+        }
+        float m = -INFINITY, l = 0.f;
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+        const uint64_t rowbase = ((uint64_t)blockIdx.x * S + (uint64_t)q) * S;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 s16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s16[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + c) * LDK + 16 * s + 8 * h);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * 32 + acc_row(i, h);
+                if (Ms[key]) s16[i] = -INFINITY;
+                mt = fmaxf(mt, s16[i]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(m, mt);
+            const float mref = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = exp2f(m - mref);
+            float lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = exp2f(s16[i] - mref);
+                lt += p;
+                s16[i] = p;
+            }
+            lt += __shfl_xor(lt, 32, 64);
+            l = l * alpha + lt;
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            if (drop.p > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[i] *= drop_factor(drop, rowbase + (uint64_t)(kt * 32 + acc_row(i, h)), 1.f);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = frag_transposed(Vt, LDV, min(dt * 32 + c, DH - 1), kt * 32, s2, h);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < S) {
+            const float inv = ks / l;
+            float* out = ctx + ((long)n * S + q) * E + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv};
+                        *reinterpret_cast<f32x4*>(out + d) = v;
+                    }
+                }
+            if (h == 0) lse2[(long)blockIdx.x * S + q] = m + log2f(l);
+        }
+    }
+}
+
+// delta[n,h,q] = sum_d dO[n,q,h*DH+d] * O[n,q,h*DH+d]
+__global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta,
+                                  long rows, int S, int E, int nh) {
+    const int dh = E / nh;
+    const long total = rows * nh;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / nh;
+        const int hd = (int)(i % nh);
+        const float* a = dO + row * E + hd * dh;
+        const float* b = O + row * E + hd * dh;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s += a[d] * b[d];
+        const long n = row / S, q = row % S;
+        delta[(n * nh + hd) * S + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dQ: same orientation as forward.  LDS: K row-major, V row-major, K transposed.
+// ------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                          const uint8_t* __restrict__ mask, int mask_B,
+                                                          float* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32;
+    constexpr int LDK = DH + 8;
+    const int LDT = Sp + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vs = Ks + Sp * LDK;
+    __bf16* Kt = Vs + Sp * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Kt + DH * LDT);
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)n * S * ld + hd * DH;
+    stage_rows<DH>(Ks, base + E, ld, S, Sp, tid, 256);
+    stage_rows<DH>(Vs, base + 2 * E, ld, S, Sp, tid, 256);
+    stage_transposed<DH>(Kt, base + E, ld, S, Sp, tid, 256);
+    for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 32 + c;
+        bf16x8 qf[KS], df[KS];
+        float L2 = 0.f, dl = 0.f;
+        if (q < S) {
+            L2 = lse2[(long)blockIdx.x * S + q];
+            dl = delta[(long)blockIdx.x * S + q];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < S) {
+                const float* qp = base + (long)q * ld + 16 * s + 8 * h;
+                const float* dp = dctx + ((long)n * S + q) * E + hd * DH + 16 * s + 8 * h;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(qp), hi = *reinterpret_cast<const f32x4*>(qp + 4);
+                const f32x4 dlo = *reinterpret_cast<const f32x4*>(dp), dhi = *reinterpret_cast<const f32x4*>(dp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; w[j] = dlo[j]; w[4 + j] = dhi[j]; }
+            }
+            qf[s] = frag_from_f32(v);
+            df[s] = frag_from_f32(w);
+        }
+        f32x16 dQ[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+        const uint64_t rowbase = ((uint64_t)blockIdx.x * S + (uint64_t)q) * S;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + c) * LDK + 16 * s + 8 * h);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + c) * LDK + 16 * s + 8 * h);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+                dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * 32 + acc_row(i, h);
+                const float p = Ms[key] ? 0.f : exp2f(s16[i] - L2);
+                float dp = dp16[i];
+                if (drop.p > 0.f) dp *= drop_factor(drop, rowbase + (uint64_t)key, ks);
+                s16[i] = p * (dp - dl) * scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 kf = frag_transposed(Kt, LDT, min(dt * 32 + c, DH - 1), kt * 32, s2, h);
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < S) {
+            float* out = dqkv + ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {dQ[dt][4 * g], dQ[dt][4 * g + 1], dQ[dt][4 * g + 2], dQ[dt][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(out + d) = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dK / dV: keys on the lanes.  One workgroup of 3 waves per (sample, head); in round r wave w
+// owns key tile 3r+w and keeps its dK^T, dV^T [dh x 32 keys] in accumulators while the workgroup
+// streams every query tile (Q, dO staged row-major AND transposed in LDS, double buffered).
+// ------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(192) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                           const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                           const uint8_t* __restrict__ mask, int mask_B,
+                                                           float* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
+    constexpr int LDR = DH + 8;      // row-major tile [32][DH+8]
+    constexpr int LDC = 32 + 8;      // transposed tile [DH][32+8]
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Qr[2][32 * LDR];
+    __shared__ __attribute__((aligned(16))) __bf16 Dr[2][32 * LDR];
+    __shared__ __attribute__((aligned(16))) __bf16 Qc[2][DH * LDC];
+    __shared__ __attribute__((aligned(16))) __bf16 Dc[2][DH * LDC];
+    __shared__ float Ls[2][32], Dl[2][32];
+
+    const int Sp = (S + 31) / 32 * 32;
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)n * S * ld + hd * DH;
+    const float* dbase = dctx + (long)n * S * E + hd * DH;
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const int rounds = (nkt + 2) / 3;
+
+    auto stage = [&](int buf, int qt) {
+        const float* qsrc = base + (long)qt * 32 * ld;
+        const float* dsrc = dbase + (long)qt * 32 * E;
+        const int rows = min(32, S - qt * 32);
+        stage_rows<DH>(Qr[buf], qsrc, ld, rows, 32, tid, 192);
+        stage_rows<DH>(Dr[buf], dsrc, E, rows, 32, tid, 192);
+        stage_transposed<DH>(Qc[buf], qsrc, ld, rows, 32, tid, 192);
+        stage_transposed<DH>(Dc[buf], dsrc, E, rows, 32, tid, 192);
+        if (tid < 32) {
+            const int q = qt * 32 + tid;
+            Ls[buf][tid] = q < S ? lse2[(long)blockIdx.x * S + q] : 0.f;
+            Dl[buf][tid] = q < S ? delta[(long)blockIdx.x * S + q] : 0.f;
+        }
+    };
+
+    for (int r = 0; r < rounds; ++r) {
+        const int kt = 3 * r + wave;
+        const bool active = kt < nkt;
+        const int key = kt * 32 + c;
+        const bool kvalid = active && key < S && !(mask && mask[(long)(n % mask_B) * S + key]);
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (active && key < S) {
+                const float* kp = base + (long)key * ld + E + 16 * s + 8 * h;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(kp), hi = *reinterpret_cast<const f32x4*>(kp + 4);
+                const f32x4 vlo = *reinterpret_cast<const f32x4*>(kp + E), vhi = *reinterpret_cast<const f32x4*>(kp + E + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = vlo[j]; w[4 + j] = vhi[j]; }
+            }
+            kf[s] = frag_from_f32(v);
+            vf[s] = frag_from_f32(w);
+        }
+        f32x16 dK[DT], dV[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
+
+        __syncthreads();            // previous round's readers are done with both buffers
+        stage(0, 0);
+        __syncthreads();
+        for (int qt = 0; qt < nqt; ++qt) {
+            const int buf = qt & 1;
+            if (qt + 1 < nqt) stage(buf ^ 1, qt + 1);
+            if (active) {
+                f32x16 s16, dp16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr[buf] + c * LDR + 16 * s + 8 * h);
+                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(Dr[buf] + c * LDR + 16 * s + 8 * h);
+                    s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], s16, 0, 0, 0);
+                    dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp16, 0, 0, 0);
+                }
+                f32x16 pd16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = acc_row(i, h);
+                    const int q = qt * 32 + row;
+                    float p = 0.f, pd = 0.f, ds = 0.f;
+                    if (kvalid && q < S) {
+                        p = exp2f(s16[i] * sc - Ls[buf][row]);
+                        const float kf_ = drop.p > 0.f ? drop_factor(drop, ((uint64_t)blockIdx.x * S + (uint64_t)q) * S + (uint64_t)key, ks) : 1.f;
+                        pd = p * kf_;
+                        ds = p * (dp16[i] * kf_ - Dl[buf][row]) * scale;
+                    }
+                    pd16[i] = pd;
+                    s16[i] = ds;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = frag_from_acc(pd16, s2);
+                    const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8 dof = frag_transposed(Dc[buf], LDC, min(dt * 32 + c, DH - 1), 0, s2, h);
+                        const bf16x8 qtf = frag_transposed(Qc[buf], LDC, min(dt * 32 + c, DH - 1), 0, s2, h);
+                        dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
+                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (active && key < S) {
+            float* outk = dqkv + ((long)n * S + key) * ld + E + hd * DH;
+            float* outv = outk + E;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 a = {dK[dt][4 * g], dK[dt][4 * g + 1], dK[dt][4 * g + 2], dK[dt][4 * g + 3]};
+                        f32x4 b = {dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2], dV[dt][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(outk + d) = a;
+                        *reinterpret_cast<f32x4*>(outv + d) = b;
+                    }
+                }
+        }
+    }
+}
+
+size_t fwd_smem(int S, int DH) {
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 16;
+}
+size_t dq_smem(int S, int DH) {
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 16;
+}
+
+template <typename K>
+int set_smem(K kernel, size_t bytes) {
+    GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+}  // namespace
+
+bool flash_attn_supported(int S, int E, int nh) {
+    if (nh <= 0 || E % nh) return false;
+    const int dh = E / nh;
+    if (!(dh == 16 || dh == 32 || dh == 64)) return false;
+    if (E % 4) return false;
+    return dq_smem(S, dh) <= 160 * 1024 && fwd_smem(S, dh) <= 160 * 1024;
+}
+
+int flash_attn_fwd(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
+                   DropKey drop, hipStream_t st) {
+    GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
+    const int dh = E / nh;
+    const size_t sm = fwd_smem(S, dh);
+    const dim3 grid((unsigned)(N * nh));
+#define GG_FWD(D)                                                                                          \
+    do {                                                                                                   \
+        GG_TRY(set_smem(&attn_fwd_kernel<D>, sm));                                                         \
+        hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop); \
+    } while (0)
+    if (dh == 64) GG_FWD(64);
+    else if (dh == 32) GG_FWD(32);
+    else GG_FWD(16);
+#undef GG_FWD
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                   int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st) {
+    GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
+    const int dh = E / nh;
+    {
+        const long total = N * S * nh;
+        unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 16384);
+        attn_delta_kernel<<<nb, 256, 0, st>>>(dctx, ctx, delta, N * S, S, E, nh);
+        GG_CHECK_HIP(hipGetLastError());
+    }
+    const size_t sm = dq_smem(S, dh);
+    const dim3 grid((unsigned)(N * nh));
+#define GG_BWD(D)                                                                                                        \
+    do {                                                                                                                 \
+        GG_TRY(set_smem(&attn_bwd_dq_kernel<D>, sm));                                                                    \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), sm, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, dim3(192), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
+    } while (0)
+    if (dh == 64) GG_BWD(64);
+    else if (dh == 32) GG_BWD(32);
+    else GG_BWD(16);
+#undef GG_BWD
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gg

@@ -60,12 +60,13 @@ struct Net {
 };
 
 struct LayerActs {
-    float *qkv, *P, *ctx, *r1, *x1, *h, *r2, *x2, *st1, *st2;
+    float *qkv, *P, *ctx, *r1, *x1, *h, *r2, *x2, *st1, *st2, *lse;
 };
 struct CondActs {
     int B = 0, R = 1, P = 0, T = 0;
     uint32_t call = 0;
     float drop = 0.f;
+    bool flash = false;
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     uint8_t* mask;
     LayerActs L[MAXL];
@@ -119,6 +120,8 @@ struct gg_engine {
     float *sumsq;              // [4]
     // conditioning backward scratch
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
+    float *s_delta;
+    int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
     float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
     // live profiling
@@ -204,6 +207,7 @@ void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
         L.x2 = a.take<float>(RB * S * E);
         L.st1 = a.take<float>(RB * S * 2);
         L.st2 = a.take<float>(RB * S * 2);
+        L.lse = a.take<float>(RB * nh * S);
     }
     c.t2i_q = a.take<float>(RB * E);
     c.t2i_kv = a.take<float>(RB * S * 2 * E);
@@ -259,6 +263,7 @@ size_t carve(gg_engine* e, void* base) {
     e->s_mod = a.take<float>(B * P * Dp);
     e->s_dmod = a.take<float>(B * P * Dp);
     e->s_dgb = a.take<float>(B * 2 * Dp);
+    e->s_delta = a.take<float>(Rb * nh * S);
     return a.off + 256;
 }
 
@@ -390,30 +395,36 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
         tok = a.tokrep;
     }
     const float scale = 1.f / sqrtf((float)dh);
+    const bool use_flash = e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(S, E, nh);
+    a.flash = use_flash;
     for (int l = 0; l < e->nl; ++l) {
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
         GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E));
-        {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
-            GemmP p;
-            p.A = L.qkv; p.B = L.qkv + E; p.C = L.P; p.M = S; p.N = S; p.K = dh;
-            p.lda = 3 * E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
-            p.batch = (int)(RB * nh); p.batch_inner = nh;
-            p.sAo = (long)S * 3 * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh;
-            p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
-            p.alpha = scale; p.colmask = a.mask; p.colmask_stride = S; p.colmask_mod = B;
-            GG_TRY(run_gemm(c, p));
-        }
         const DropKey kA = dkey(e, a, n.role, l, 0);
-        KL(k_softmax_rows(L.P, e->sPd, RB * nh * S, S, kA, c.st));
-        {   // ctx[b,:,h] = Pd[b,h] V_h
-            GemmP p;
-            p.A = drop > 0.f ? e->sPd : L.P; p.B = L.qkv + 2 * E; p.C = L.ctx; p.M = S; p.N = dh; p.K = S;
-            p.lda = S; p.ldb = 3 * E; p.ldc = E; p.layA = LAY_KC; p.layB = LAY_KS;
-            p.batch = (int)(RB * nh); p.batch_inner = nh;
-            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh;
-            p.sCo = (long)S * E; p.sCi = dh;
-            GG_TRY(run_gemm(c, p));
+        if (use_flash) {
+            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, c.st));
+        } else {
+            {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
+                GemmP p;
+                p.A = L.qkv; p.B = L.qkv + E; p.C = L.P; p.M = S; p.N = S; p.K = dh;
+                p.lda = 3 * E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
+                p.batch = (int)(RB * nh); p.batch_inner = nh;
+                p.sAo = (long)S * 3 * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh;
+                p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
+                p.alpha = scale; p.colmask = a.mask; p.colmask_stride = S; p.colmask_mod = B;
+                GG_TRY(run_gemm(c, p));
+            }
+            KL(k_softmax_rows(L.P, e->sPd, RB * nh * S, S, kA, c.st));
+            {   // ctx[b,:,h] = Pd[b,h] V_h
+                GemmP p;
+                p.A = drop > 0.f ? e->sPd : L.P; p.B = L.qkv + 2 * E; p.C = L.ctx; p.M = S; p.N = dh; p.K = S;
+                p.lda = S; p.ldb = 3 * E; p.ldc = E; p.layA = LAY_KC; p.layB = LAY_KS;
+                p.batch = (int)(RB * nh); p.batch_inner = nh;
+                p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh;
+                p.sCo = (long)S * E; p.sCi = dh;
+                GG_TRY(run_gemm(c, p));
+            }
         }
         GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
         KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
@@ -502,45 +513,50 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         KL(k_colsum(e->sdres, RB * S, E, E, g + lp.sa.ob, c.st));
         GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E));
         const DropKey kA = dkey(e, a, n.role, l, 0);
-        const float* Pd = L.P;
-        if (drop > 0.f) {
-            KL(k_dropout_copy(e->sPd, L.P, RB * nh * S * S, kA, c.st));
-            Pd = e->sPd;
-        }
-        GemmP p;
-        const int nb = (int)(RB * nh);
-        {   // dPd = dctx_h V_h^T
-            p = GemmP();
-            p.A = e->sdctx; p.B = L.qkv + 2 * E; p.C = e->sdP; p.M = S; p.N = S; p.K = dh;
-            p.lda = E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
-            p.batch = nb; p.batch_inner = nh;
-            p.sAo = (long)S * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
-            GG_TRY(run_gemm(c, p));
-        }
-        {   // dV_h = Pd^T dctx_h
-            p = GemmP();
-            p.A = Pd; p.B = e->sdctx; p.C = e->sdqkv + 2 * E; p.M = S; p.N = dh; p.K = S;
-            p.lda = S; p.ldb = E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
-            p.batch = nb; p.batch_inner = nh;
-            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
-            GG_TRY(run_gemm(c, p));
-        }
-        KL(k_softmax_bwd_rows(e->sdP, L.P, (long)nb * S, S, 1.f / sqrtf((float)dh), kA, c.st));
-        {   // dQ_h = dS K_h
-            p = GemmP();
-            p.A = e->sdP; p.B = L.qkv + E; p.C = e->sdqkv; p.M = S; p.N = dh; p.K = S;
-            p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KC; p.layB = LAY_KS;
-            p.batch = nb; p.batch_inner = nh;
-            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
-            GG_TRY(run_gemm(c, p));
-        }
-        {   // dK_h = dS^T Q_h
-            p = GemmP();
-            p.A = e->sdP; p.B = L.qkv; p.C = e->sdqkv + E; p.M = S; p.N = dh; p.K = S;
-            p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
-            p.batch = nb; p.batch_inner = nh;
-            p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
-            GG_TRY(run_gemm(c, p));
+        if (a.flash) {
+            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, c.st));
+            c.e->launches += 2;
+        } else {
+            const float* Pd = L.P;
+            if (drop > 0.f) {
+                KL(k_dropout_copy(e->sPd, L.P, RB * nh * S * S, kA, c.st));
+                Pd = e->sPd;
+            }
+            GemmP p;
+            const int nb = (int)(RB * nh);
+            {   // dPd = dctx_h V_h^T
+                p = GemmP();
+                p.A = e->sdctx; p.B = L.qkv + 2 * E; p.C = e->sdP; p.M = S; p.N = S; p.K = dh;
+                p.lda = E; p.ldb = 3 * E; p.ldc = S; p.layA = LAY_KC; p.layB = LAY_KC;
+                p.batch = nb; p.batch_inner = nh;
+                p.sAo = (long)S * E; p.sAi = dh; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)nh * S * S; p.sCi = (long)S * S;
+                GG_TRY(run_gemm(c, p));
+            }
+            {   // dV_h = Pd^T dctx_h
+                p = GemmP();
+                p.A = Pd; p.B = e->sdctx; p.C = e->sdqkv + 2 * E; p.M = S; p.N = dh; p.K = S;
+                p.lda = S; p.ldb = E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
+                p.batch = nb; p.batch_inner = nh;
+                p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+                GG_TRY(run_gemm(c, p));
+            }
+            KL(k_softmax_bwd_rows(e->sdP, L.P, (long)nb * S, S, 1.f / sqrtf((float)dh), kA, c.st));
+            {   // dQ_h = dS K_h
+                p = GemmP();
+                p.A = e->sdP; p.B = L.qkv + E; p.C = e->sdqkv; p.M = S; p.N = dh; p.K = S;
+                p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KC; p.layB = LAY_KS;
+                p.batch = nb; p.batch_inner = nh;
+                p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+                GG_TRY(run_gemm(c, p));
+            }
+            {   // dK_h = dS^T Q_h
+                p = GemmP();
+                p.A = e->sdP; p.B = L.qkv; p.C = e->sdqkv + E; p.M = S; p.N = dh; p.K = S;
+                p.lda = S; p.ldb = 3 * E; p.ldc = 3 * E; p.layA = LAY_KS; p.layB = LAY_KS;
+                p.batch = nb; p.batch_inner = nh;
+                p.sAo = (long)nh * S * S; p.sAi = (long)S * S; p.sBo = (long)S * 3 * E; p.sBi = dh; p.sCo = (long)S * 3 * E; p.sCi = dh;
+                GG_TRY(run_gemm(c, p));
+            }
         }
         GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E));
         KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st));
@@ -870,6 +886,11 @@ int gg_set_dropout(gg_engine* e, float p) {
 int gg_set_precision(gg_engine* e, int precision) {
     GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16), "bad precision");
     e->precision = precision;
+    return 0;
+}
+int gg_set_flash(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->flash = on != 0;
     return 0;
 }
 int gg_set_seed(gg_engine* e, uint64_t seed) {

@@ -95,6 +95,15 @@ int k_row_sumsq(const float* X, float* out, long rows, int N, hipStream_t st);
 // coef[r] = gp_weight*(2/B)*(nrm-1)/nrm ; losses[2] += mean((nrm-1)^2)
 int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_weight, hipStream_t st);
 
+// fused self-attention (attention.hip): bf16 MFMA, no [S,S] tensor in HBM -----------------------------------
+bool flash_attn_supported(int S, int E, int nh);
+// qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S]
+int flash_attn_fwd(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
+                   DropKey drop, hipStream_t st);
+// dctx [N,S,E] -> dqkv [N,S,3E] (fully overwritten); delta [N,nh,S] scratch
+int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                   int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st);
+
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
 enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };

@@ -152,6 +152,9 @@ class Engine:
         L.check(self.lib.gg_set_precision(self.h, L.PRECISIONS[precision]))
         self.precision = precision
 
+    def set_flash(self, on: bool):
+        L.check(self.lib.gg_set_flash(self.h, int(on)))
+
     def set_seed(self, seed):
         L.check(self.lib.gg_set_seed(self.h, C.c_uint64(seed)))
 

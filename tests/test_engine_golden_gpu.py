@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
+def well_conditioned(grad):
+    """The first RMSprop step is -lr*g/(0.1|g|+1e-8): for |g| <~ 1e-6 the update depends on the VALUE of a
+    gradient that is itself rounding noise in fp32 (any summation order moves it), so post-step parameters
+    are compared where the golden gradient is at least 1e-5 of its tensor's scale and above 1e-6 absolute."""
+    a = np.abs(np.asarray(grad, dtype=np.float64)).reshape(-1)
+    return (a > 1e-5 * max(a.max(), 1e-30)) & (a > 1e-6)
+
+
 def make(g: Golden, opt="rms_prop"):
     cfg = g.cfg(opt)
     d = g.dims
@@ -66,7 +74,10 @@ def test_critic_iteration(name):
     eng.critic_apply(1.0)
     post = eng.state(L.ROLE_CRITIC, "w")
     for n, r in g.group("critic1/post_disc").items():
+        if n not in post:
+            continue          # dead patches_transformer_layer.* template copy (never trained, not in the engine)
         keep = comparable(n, post[n], g.dims["E"])[::3]
+        keep &= well_conditioned(g.z["critic1/grad/" + n])[::3]
         ck.check("post-step " + n, post[n].reshape(-1)[::3].cpu().numpy()[keep], r[keep])
     ck.done()
 
@@ -84,7 +95,10 @@ def test_generator_iteration(name):
     eng.generator_apply(1.0)
     post = eng.state(L.ROLE_GENERATOR, "w")
     for n, r in g.group("gen1/post_gen").items():
+        if n not in post:
+            continue
         keep = comparable(n, post[n], g.dims["E"])[::3]
+        keep &= well_conditioned(g.z["gen1/grad/" + n])[::3]
         ck.check("post-step " + n, post[n].reshape(-1)[::3].cpu().numpy()[keep], r[keep])
     ck.done()
 
@@ -111,6 +125,8 @@ def test_full_train_step(name, opt):
         post = eng.state(role, "w")
         init = g.group(f"init_{prefix}")
         for n, r in g.group(f"step_{opt}/post_{prefix}").items():
+            if n not in post:
+                continue
             keep = comparable(n, post[n], g.dims["E"])[::stride]
             a = post[n].reshape(-1)[::stride].cpu().numpy()[keep]
             r = r.reshape(-1)[keep]
