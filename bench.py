@@ -112,12 +112,21 @@ def main():
             cpu = {"error": repr(ex)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if os.environ.get("GG_BENCH_BACKEND", "nccl") != "nccl" and ndev > 0:
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  GG_BENCH_BACKEND=gloo lets several ranks share ONE GPU to rehearse the
+        # data-parallel path on a single-GPU box (never used for reported numbers).
+        backend = os.environ.get("GG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import gemm_gan_amd as gga
     G, B, P, T = args.genes, args.batch, args.patches, args.tokens

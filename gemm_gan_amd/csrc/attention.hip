@@ -56,6 +56,8 @@ __device__ __forceinline__ bf16x8 frag_from_acc(const f32x16& a, int s2) {   // 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 constexpr float LOG2E = 1.4426950408889634f;
+// raw v_exp_f32 (2^x): inputs here are <= 0 or -inf; flush-to-zero of tiny results is harmless for softmax
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- LDS staging -------------------------------------------------------------------------------------
 // row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled
@@ -176,11 +178,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mn = fmaxf(m, mt);
             const float mref = (mn == -INFINITY) ? 0.f : mn;
-            const float alpha = exp2f(m - mref);
+            const float alpha = fast_exp2(m - mref);
             float lt = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = exp2f(s16[i] - mref);
+                const float p = fast_exp2(s16[i] - mref);
                 lt += p;
                 s16[i] = p;
             }
@@ -244,8 +246,9 @@ __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __r
 // backward, dQ: same orientation as forward.  LDS: K row-major, V row-major, K transposed.
 // ------------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                          const float* __restrict__ dctx,
+                                                          const float* __restrict__ lse2, float* __restrict__ delta,
                                                           const uint8_t* __restrict__ mask, int mask_B,
                                                           float* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -278,24 +281,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         const int q = qt * 32 + c;
         bf16x8 qf[KS], df[KS];
         float L2 = 0.f, dl = 0.f;
-        if (q < S) {
-            L2 = lse2[(long)blockIdx.x * S + q];
-            dl = delta[(long)blockIdx.x * S + q];
-        }
+        if (q < S) L2 = lse2[(long)blockIdx.x * S + q];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (q < S) {
                 const float* qp = base + (long)q * ld + 16 * s + 8 * h;
-                const float* dp = dctx + ((long)n * S + q) * E + hd * DH + 16 * s + 8 * h;
+                const long off = ((long)n * S + q) * E + hd * DH + 16 * s + 8 * h;
+                const float* dp = dctx + off;
+                const float* op = ctx + off;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(qp), hi = *reinterpret_cast<const f32x4*>(qp + 4);
                 const f32x4 dlo = *reinterpret_cast<const f32x4*>(dp), dhi = *reinterpret_cast<const f32x4*>(dp + 4);
+                const f32x4 olo = *reinterpret_cast<const f32x4*>(op), ohi = *reinterpret_cast<const f32x4*>(op + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; w[j] = dlo[j]; w[4 + j] = dhi[j]; }
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; w[j] = dlo[j]; w[4 + j] = dhi[j];
+                    dl += dlo[j] * olo[j] + dhi[j] * ohi[j];
+                }
             }
             qf[s] = frag_from_f32(v);
             df[s] = frag_from_f32(w);
         }
+        // delta[q] = sum_d dO*O : this lane-half covered half of the head dim, the other half the rest
+        dl += __shfl_xor(dl, 32, 64);
+        if (q < S && h == 0) delta[(long)blockIdx.x * S + q] = dl;      // consumed by the dK/dV kernel
         f32x16 dQ[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kt * 32 + acc_row(i, h);
-                const float p = Ms[key] ? 0.f : exp2f(s16[i] - L2);
+                const float p = Ms[key] ? 0.f : fast_exp2(s16[i] - L2);
                 float dp = dp16[i];
                 if (drop.p > 0.f) dp *= drop_factor(drop, rowbase + (uint64_t)key, ks);
                 s16[i] = p * (dp - dl) * scale;
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(192) void attn_bwd_dkv_kernel(const float* __restri
                     const int q = qt * 32 + row;
                     float p = 0.f, pd = 0.f, ds = 0.f;
                     if (kvalid && q < S) {
-                        p = exp2f(s16[i] * sc - Ls[buf][row]);
+                        p = fast_exp2(s16[i] * sc - Ls[buf][row]);
                         const float kf_ = drop.p > 0.f ? drop_factor(drop, ((uint64_t)blockIdx.x * S + (uint64_t)q) * S + (uint64_t)key, ks) : 1.f;
                         pd = p * kf_;
                         ds = p * (dp16[i] * kf_ - Dl[buf][row]) * scale;
@@ -533,18 +542,12 @@ int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const 
                    int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st) {
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
-    {
-        const long total = N * S * nh;
-        unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 16384);
-        attn_delta_kernel<<<nb, 256, 0, st>>>(dctx, ctx, delta, N * S, S, E, nh);
-        GG_CHECK_HIP(hipGetLastError());
-    }
     const size_t sm = dq_smem(S, dh);
     const dim3 grid((unsigned)(N * nh));
 #define GG_BWD(D)                                                                                                        \
     do {                                                                                                                 \
         GG_TRY(set_smem(&attn_bwd_dq_kernel<D>, sm));                                                                    \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), sm, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, dim3(192), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
     } while (0)
     if (dh == 64) GG_BWD(64);

@@ -43,6 +43,11 @@ struct Net {
     long w1, b1, w2, b2, w3, b3;
     int V = 0, OUT = 0;            // first-layer non-conditioning width (L or G), output width (G or 1)
     float *w = nullptr, *g = nullptr, *s1 = nullptr, *s2 = nullptr;
+    // bf16 shadow copies of the 2-D conditioning-stack weights (same offsets as the flat fp32 buffer):
+    // wb = W [rows][cols], wtb = W^T [cols][rows]; refreshed from the fp32 master at every public entry
+    char *wb = nullptr, *wtb = nullptr;
+    ShadowEntry* tab_dev = nullptr;
+    std::vector<ShadowEntry> tab;
     int step_t = 0;
     float lr = 0.f;
 
@@ -53,7 +58,7 @@ struct Net {
         p.shape[0] = d0; p.shape[1] = d1; p.shape[2] = d2;
         p.numel = (long)d0 * (d1 ? d1 : 1) * (d2 ? d2 : 1);
         p.off = total;
-        total += (p.numel + 3) / 4 * 4;     // 16-byte aligned slots: vector loads on every weight
+        total += (p.numel + 7) / 8 * 8;     // 32-byte aligned slots: 16-byte vector loads on the fp32 weights AND their bf16 shadows
         ps.push_back(p);
         return p.off;
     }
@@ -122,6 +127,7 @@ struct gg_engine {
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
     float *s_delta;
     int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
+    int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
     float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
     // live profiling
@@ -183,6 +189,12 @@ void build_net(gg_engine* e, int role) {
     n.b2 = n.add(mlp + ".1.0.bias", H);
     n.w3 = n.add("final_layer.weight", n.OUT, H);
     n.b3 = n.add("final_layer.bias", n.OUT);
+    // 2-D weights of the conditioning stack get bf16 shadows (the MLP head products are short-M and stay generic)
+    for (const ParamInfo& pi : n.ps) {
+        if (pi.ndim != 2) continue;
+        if (pi.off == n.w1 || pi.off == n.w2 || pi.off == n.w3) continue;
+        n.tab.push_back(ShadowEntry{pi.off, pi.shape[0], pi.shape[1]});
+    }
 }
 
 void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
@@ -230,6 +242,12 @@ size_t carve(gg_engine* e, void* base) {
     const long P = e->maxP, Dp = e->Dp;
     carve_cond(e, a, e->actsG, 1);
     carve_cond(e, a, e->actsD, (int)R);
+    for (int r = 0; r < 2; ++r) {
+        Net& n = e->net[r];
+        n.wb = a.take<char>((size_t)n.total * 2);
+        n.wtb = a.take<char>((size_t)n.total * 2);
+        n.tab_dev = a.take<ShadowEntry>(n.tab.size() + 1);
+    }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
     e->X2 = a.take<float>(2 * B * G);
@@ -357,6 +375,50 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
         c.e->launches++;         \
     } while (0)
 
+inline bool use_tlin(gg_engine* e) { return e->tlin_on && e->precision == GG_PREC_BF16; }
+
+int refresh_shadows(Ctx& c, Net& n) {
+    if (!use_tlin(c.e) || n.tab.empty()) return 0;
+    KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
+    return 0;
+}
+inline const void* WB(const Net& n, long off) { return n.wb + 2 * off; }      // bf16 W   at flat offset `off`
+inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    // bf16 W^T at flat offset `off`
+
+// launches the token-on-lane kernel when enabled and the shape qualifies; returns 1 if it ran
+int try_tlin(Ctx& c, const TlinP& p) {
+    if (!use_tlin(c.e) || !tlin_supported(p)) return 0;
+    c.e->launches++;
+    if (c.e->prof_on) {
+        gg_engine* e = c.e;
+        if (e->prof_next + 2 > e->prof_pool.size()) {
+            for (int i = 0; i < 4096; ++i) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return -1;
+                e->prof_pool.push_back(ev);
+            }
+        }
+        gg_engine::ProfRec r;
+        r.cls = 8 + ((p.ln_g || p.res || p.K > 256) ? 1 : 0);
+        r.flops = 2.0 * p.M * p.N * (double)p.K;
+        r.bytes = 4.0 * ((double)p.M * p.K + (double)p.M * p.N * (p.ln_g ? 2 : 1) + (p.res ? (double)p.M * p.N : 0) + (p.mask_ref ? (double)p.M * p.N : 0)) + 2.0 * p.N * p.K;
+        r.e0 = e->prof_pool[e->prof_next++];
+        r.e1 = e->prof_pool[e->prof_next++];
+        if (hipEventRecord(r.e0, c.st) != hipSuccess) return -1;
+        if (tlin(p, c.st) != 0) return -1;
+        if (hipEventRecord(r.e1, c.st) != hipSuccess) return -1;
+        e->prof_recs.push_back(r);
+        return 1;
+    }
+    return tlin(p, c.st) == 0 ? 1 : -1;
+}
+#define TLIN_OR(p_, fallback)                 \
+    do {                                      \
+        const int _t = try_tlin(c, p_);       \
+        if (_t < 0) return -1;                \
+        if (_t == 0) { fallback; }            \
+    } while (0)
+
 DropKey dkey(gg_engine* e, const CondActs& a, int net, int layer, int site) {
     return make_drop_key(a.drop, e->seed, (uint32_t)(net * 1000 + layer * 10 + site), a.call);
 }
@@ -378,11 +440,15 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt));
     // patch encoder with FiLM fused on the A operand; rows land behind the CLS row of each sample
     {
+        TlinP t;
+        t.X = in->patches; t.ldx = Dp; t.M = (long)B * P; t.W = WB(n, n.pe_w); t.ldw = Dp; t.bias = w + n.pe_b;
+        t.Y = a.x0; t.ldy = E; t.N = E; t.K = Dp;
+        t.film_g = a.gb; t.film_b = a.gb + Dp; t.film_ld = 2 * Dp; t.film_group = P; t.y_row_group = P;
         GemmP p;
         p.A = in->patches; p.B = w + n.pe_w; p.C = a.x0; p.M = B * P; p.N = E; p.K = Dp;
         p.lda = Dp; p.ldb = Dp; p.ldc = E; p.bias = w + n.pe_b;
         p.film_gamma = a.gb; p.film_beta = a.gb + Dp; p.film_ld = 2 * Dp; p.film_group = P; p.c_row_group = P;
-        GG_TRY(run_gemm(c, p));
+        TLIN_OR(t, GG_TRY(run_gemm(c, p)));
     }
     KL(k_write_cls(a.x0, w + n.cls, B, S, E, c.st));
     KL(k_build_mask(in->patch_pad, a.mask, B, P, c.st));
@@ -400,7 +466,12 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     for (int l = 0; l < e->nl; ++l) {
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
-        GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E));
+        {
+            TlinP t;
+            t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
+            t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E;
+            TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
+        }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (use_flash) {
             KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, c.st));
@@ -426,17 +497,47 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 GG_TRY(run_gemm(c, p));
             }
         }
-        GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
-        KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
-        GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
-        if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
-        GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
-        KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
+        {   // x1 = LN1(x + drop(ctx Wo^T + bo)) : Linear, dropout, residual and LayerNorm in one kernel
+            TlinP t;
+            t.X = L.ctx; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.ow); t.ldw = E; t.bias = w + lp.sa.ob;
+            t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
+            t.res = x_in; t.ldres = E; t.res_rows = RB * S;
+            t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1;
+            TLIN_OR(t, {
+                GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
+                KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
+            });
+        }
+        {   // h = drop(relu(x1 W1^T + b1))
+            TlinP t;
+            t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
+            t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
+            TLIN_OR(t, {
+                GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
+                if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
+            });
+        }
+        {   // x2 = LN2(x1 + drop(h W2^T + b2))
+            TlinP t;
+            t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
+            t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
+            t.res = L.x1; t.ldres = E; t.res_rows = RB * S;
+            t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2;
+            TLIN_OR(t, {
+                GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
+                KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
+            });
+        }
         x_in = L.x2;
     }
     // T2I: query = text CLS embedding, keys = values = encoder output (R:218)
     GG_TRY(lin_fwd(c, tok, (long)T * E, w + n.t2i.inw, E, w + n.t2i.inb, a.t2i_q, E, (int)RB, E, E));
-    GG_TRY(lin_fwd(c, x_in, E, w + n.t2i.inw + (long)E * E, E, w + n.t2i.inb + E, a.t2i_kv, 2 * E, (int)(RB * S), 2 * E, E));
+    {
+        TlinP t;
+        t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, n.t2i.inw + (long)E * E); t.ldw = E; t.bias = w + n.t2i.inb + E;
+        t.Y = a.t2i_kv; t.ldy = 2 * E; t.N = 2 * E; t.K = E;
+        TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + n.t2i.inw + (long)E * E, E, w + n.t2i.inb + E, a.t2i_kv, 2 * E, (int)(RB * S), 2 * E, E)));
+    }
     KL(k_sq_attn_fwd(a.t2i_q, a.t2i_kv, a.mask, B, a.t2i_P, a.t2i_ctx, (int)RB, S, E, nh, c.st));
     GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
     // I2T: query = that vector, keys = values = encoded text tokens (R:220)
@@ -487,7 +588,12 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
     GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
     KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
-    GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E));
+    {   // denc = dkv Wkv : reduction over the 2E projected features, W^T = columns E..3E of in_proj^T
+        TlinP t;
+        t.X = e->s_dkv; t.ldx = 2 * E; t.M = RB * S; t.W = WTB(n, n.t2i.inw + E); t.ldw = 3 * E;
+        t.Y = e->sdx; t.ldy = E; t.N = E; t.K = 2 * E;
+        TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E)));
+    }
     // ---- encoder layers, last to first ---------------------------------------------------------------
     float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
     for (int l = e->nl - 1; l >= 0; --l) {
@@ -495,23 +601,38 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         const LayerP& lp = n.layer[l];
         const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 ? a.xrep : a.x0);
         // LN2
-        KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, RB * S, E,
+        KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
                            dkey(e, a, n.role, l, 3), c.st));
-        // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))
+        // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))   (db2 = column sums of df: fused above)
         GG_TRY(lin_bwd_weight(c, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F));
-        KL(k_colsum(e->sdres, RB * S, E, E, g + lp.l2b, c.st));
-        GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.l2w, F, e->sdh, F, (int)(RB * S), E, F));
-        KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));      // (h>0) covers ReLU and the kept-mask
+        {   // dhpre = (df W2) * [h > 0] / (1-p) : the stored post-dropout h gates both ReLU and the kept-mask
+            TlinP t;
+            t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.l2w); t.ldw = E;
+            t.Y = e->sdh; t.ldy = F; t.N = F; t.K = E; t.mask_ref = L.h; t.ldref = F; t.mask_scale = ks;
+            TLIN_OR(t, {
+                GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.l2w, F, e->sdh, F, (int)(RB * S), E, F));
+                KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));
+            });
+        }
         GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E));
         KL(k_colsum(e->sdh, RB * S, F, F, g + lp.l1b, c.st));
-        GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1));   // dx1 = dr2 + ...
+        {   // dx1 = dr2 + dhpre W1
+            TlinP t;
+            t.X = e->sdh; t.ldx = F; t.M = RB * S; t.W = WTB(n, lp.l1w); t.ldw = F;
+            t.Y = e->sdr; t.ldy = E; t.N = E; t.K = F; t.accumulate = 1;
+            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1)));
+        }
         // LN1
-        KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, RB * S, E,
+        KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
                            dkey(e, a, n.role, l, 1), c.st));
-        // self attention out-proj
+        // self attention out-proj   (d(out_proj.bias) fused above)
         GG_TRY(lin_bwd_weight(c, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E));
-        KL(k_colsum(e->sdres, RB * S, E, E, g + lp.sa.ob, c.st));
-        GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E));
+        {
+            TlinP t;
+            t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.sa.ow); t.ldw = E;
+            t.Y = e->sdctx; t.ldy = E; t.N = E; t.K = E;
+            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
+        }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (a.flash) {
             KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, c.st));
@@ -560,7 +681,12 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         }
         GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E));
         KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st));
-        GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1));   // dx_in = dr1 + ...
+        {   // dx_in = dr1 + dqkv Win
+            TlinP t;
+            t.X = e->sdqkv; t.ldx = 3 * E; t.M = RB * S; t.W = WTB(n, lp.sa.inw); t.ldw = 3 * E;
+            t.Y = dx; t.ldy = E; t.N = E; t.K = 3 * E; t.accumulate = 1;
+            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
+        }
     }
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
     const float* dx0 = dx;
@@ -576,7 +702,12 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     KL(k_film_mod(in->patches, a.gb, e->s_mod, B, P, Dp, c.st));
     GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
     KL(k_colsum(e->s_demb, (long)B * P, E, E, g + n.pe_b, c.st));
-    GG_TRY(lin_bwd_data(c, e->s_demb, E, w + n.pe_w, Dp, e->s_dmod, Dp, B * P, E, Dp));
+    {
+        TlinP t;
+        t.X = e->s_demb; t.ldx = E; t.M = (long)B * P; t.W = WTB(n, n.pe_w); t.ldw = E;
+        t.Y = e->s_dmod; t.ldy = Dp; t.N = Dp; t.K = E;
+        TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_demb, E, w + n.pe_w, Dp, e->s_dmod, Dp, B * P, E, Dp)));
+    }
     KL(k_film_bwd_reduce(e->s_dmod, in->patches, e->s_dgb, B, P, Dp, c.st));
     KL(k_film_act_bwd(e->s_dgb, a.gb, a.gbpre, B, Dp, c.st));
     GG_TRY(lin_bwd_weight(c, e->s_dgb, 2 * Dp, in->text, (long)T * Dt, g + n.film_w, Dt, B, 2 * Dp, Dt));
@@ -675,6 +806,8 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     const float slope = e->cfg.negative_slope;
     const int R = e->dropout > 0.f ? 3 : 1;
     GG_REQUIRE(R <= e->maxR, "workspace was sized for dropout == 0; recreate the engine with dropout > 0");
+    GG_TRY(refresh_shadows(c, e->net[GG_ROLE_GENERATOR]));
+    GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
     KL(k_fill(D.g, D.total, 0.f, c.st));
     // x_fake = G(z) (generator frozen: no activations kept beyond this call)   R:391
@@ -728,6 +861,8 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H, L = e->L;
+    GG_TRY(refresh_shadows(c, Gn));
+    GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
     KL(k_fill(Gn.g, Gn.total, 0.f, c.st));
     GG_TRY(generator_forward(c, z, in, e->X2, 1));                       // R:441 (activations kept in actsG/headG)
@@ -814,6 +949,11 @@ int gg_bind_workspace(gg_engine* e, void* ws, size_t bytes) {
     GG_REQUIRE((uintptr_t)ws % 256 == 0, "workspace must be 256-byte aligned");
     e->ws = ws;
     carve(e, ws);
+    for (int r = 0; r < 2; ++r) {
+        Net& n = e->net[r];
+        if (!n.tab.empty())
+            GG_CHECK_HIP(hipMemcpy(n.tab_dev, n.tab.data(), n.tab.size() * sizeof(ShadowEntry), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -822,6 +962,7 @@ int gg_forward(gg_engine* e, int role, const float* v, const gg_cond* in, float*
     GG_REQUIRE(role == 0 || role == 1, "bad role");
     GG_TRY(check_cond(e, in));
     Ctx c{e, (hipStream_t)stream};
+    GG_TRY(refresh_shadows(c, e->net[role]));
     if (role == GG_ROLE_GENERATOR) return generator_forward(c, v, in, out, train);
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B;
@@ -893,6 +1034,11 @@ int gg_set_flash(gg_engine* e, int on) {
     e->flash = on != 0;
     return 0;
 }
+int gg_set_tlin(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->tlin_on = on != 0;
+    return 0;
+}
 int gg_set_seed(gg_engine* e, uint64_t seed) {
     GG_REQUIRE(e, "null argument");
     e->seed = seed;
@@ -922,8 +1068,10 @@ int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
     static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                                    "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
-    e->prof_agg.assign(8, gg_engine::ProfAgg());
+    e->prof_agg.assign(10, gg_engine::ProfAgg());
     for (int i = 0; i < 8; ++i) e->prof_agg[i].name = names[i];
+    e->prof_agg[8].name = "tlin_kernel<64,stream>";
+    e->prof_agg[9].name = "tlin_kernel<32,resident>";
     for (auto& r : e->prof_recs) {
         if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("hipEventSynchronize failed"); return -1; }
         float ms = 0.f;

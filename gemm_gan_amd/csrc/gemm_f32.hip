@@ -127,7 +127,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p, const
 
     const int tid = threadIdx.x;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block
+    // b and b+8 share an L2.  Give one XCD ALL N-tiles of a row panel back to back: the A panel is
+    // then fetched from HBM once and re-read from that XCD's L2 (speed only; any placement is correct).
+    int tile_m, tile_n;
+    {
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+        const int full = (tiles_m / 8) * 8;              // row panels covered by the 8-way interleave
+        const int pm = (local / tiles_n) * 8 + xcd;
+        if (pm < full) {
+            tile_m = pm;
+            tile_n = local % tiles_n;
+        } else {                                         // tail panels (tiles_m % 8): plain order
+            const int t = bid - full * tiles_n;
+            tile_m = full + t / tiles_n;
+            tile_n = t % tiles_n;
+        }
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
     const int bz = z / p.splitk, sk = z % p.splitk;

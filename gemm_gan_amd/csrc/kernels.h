@@ -46,8 +46,10 @@ int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g,
                         float* stats, long rows, int E, DropKey drop, hipStream_t st);
 // dr = LN backward of dy wrt r (r, stats saved) ; dgamma/dbeta accumulated atomically.
 // dres_out (may be null) = drop-masked dr (gradient w.r.t. the un-dropped `res` branch)
+// dbias (may be null) += column sums of that masked branch gradient (= bias gradient of the Linear
+// that produced the residual branch), saving a separate pass over the tensor.
 int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr,
-                    float* dres_out, float* dgamma, float* dbeta, long rows, int E, DropKey drop, hipStream_t st);
+                    float* dres_out, float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st);
 
 // out[n] += sum_rows X[r, n]
 int k_colsum(const float* X, long rows, int N, long ld, float* out, hipStream_t st);
@@ -103,6 +105,28 @@ int flash_attn_fwd(const float* qkv, const uint8_t* mask, int mask_B, float* ctx
 // dctx [N,S,E] -> dqkv [N,S,3E] (fully overwritten); delta [N,nh,S] scratch
 int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
                    int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st);
+
+// token-on-lane Linear (tlin.hip): Y[M,N] = epi(X[M,K] W[N,K]^T), bf16 MFMA, activations read once ---------------
+struct TlinP {
+    const float* X = nullptr; long ldx = 0; long M = 0;
+    const void* W = nullptr; long ldw = 0;          // bf16 [N][K] (row stride ldw elements)
+    const float* bias = nullptr;
+    float* Y = nullptr; long ldy = 0;
+    int N = 0, K = 0;
+    const float* film_g = nullptr; const float* film_b = nullptr; long film_ld = 0; int film_group = 0;   // X' = g*X + b
+    int y_row_group = 0;                            // output row m -> m + m / group + 1
+    int act_relu = 0;
+    DropKey drop; long drop_ld = 0;                 // dropout of the Linear output, element index = token*drop_ld + n
+    const float* mask_ref = nullptr; long ldref = 0; float mask_scale = 1.f;   // y = ref > 0 ? y*scale : 0
+    int accumulate = 0;                             // y += previous content
+    const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
+    const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
+};
+bool tlin_supported(const TlinP& p);
+int tlin(const TlinP& p, hipStream_t st);
+// bf16 shadow copies of the 2-D weights: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows], same offsets
+struct ShadowEntry { long off; int rows, cols; };
+int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);

@@ -332,13 +332,13 @@ int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g,
 
 template <int NJ>
 __global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r, const float* stats, const float* g,
-                                                 float* dr, float* dres, float* dgamma, float* dbeta, long rows, int E,
-                                                 DropKey drop) {
+                                                 float* dr, float* dres, float* dgamma, float* dbeta, float* dbias,
+                                                 long rows, int E, DropKey drop) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-    float pg[NJ], pb[NJ];
+    float pg[NJ], pb[NJ], pc[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) pg[j] = pb[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) pg[j] = pb[j] = pc[j] = 0.f;
     for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         float xh[NJ], dxh[NJ];
@@ -365,7 +365,9 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r,
             if (c < E) {
                 const float v = rstd * (dxh[j] - s1 - xh[j] * s2);
                 dr[row * E + c] = v;
-                if (dres) dres[row * E + c] = drop.p > 0.f ? v * drop_factor(drop, (uint64_t)row * E + c, ks) : v;
+                const float vb = drop.p > 0.f ? v * drop_factor(drop, (uint64_t)row * E + c, ks) : v;
+                if (dres) dres[row * E + c] = vb;
+                pc[j] += vb;
             }
         }
     }
@@ -375,13 +377,14 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r,
         if (c < E) {
             atomicAdd(&dgamma[c], pg[j]);
             atomicAdd(&dbeta[c], pb[j]);
+            if (dbias) atomicAdd(&dbias[c], pc[j]);
         }
     }
 }
 int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, float* dres_out,
-                    float* dgamma, float* dbeta, long rows, int E, DropKey drop, hipStream_t st) {
+                    float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st) {
     const unsigned nb = nblocks(rows, 4 * 16, 4096);   // >=16 rows per wave so the atomics are amortised
-#define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dgamma, dbeta, rows, E, drop)
+#define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dgamma, dbeta, dbias, rows, E, drop)
     if (E <= 64) GG_LN_BWD(1);
     else if (E <= 128) GG_LN_BWD(2);
     else if (E <= 256) GG_LN_BWD(4);

@@ -155,6 +155,9 @@ class Engine:
     def set_flash(self, on: bool):
         L.check(self.lib.gg_set_flash(self.h, int(on)))
 
+    def set_tlin(self, on: bool):
+        L.check(self.lib.gg_set_tlin(self.h, int(on)))
+
     def set_seed(self, seed):
         L.check(self.lib.gg_set_seed(self.h, C.c_uint64(seed)))
 

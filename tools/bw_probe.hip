@@ -1,0 +1,65 @@
+// Access-pattern bandwidth probe for MI355X (tools only).  hipcc --offload-arch=gfx950 -O3 bw_probe.hip -o bw_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// (a) a wave reads 64 consecutive rows of a [M][K] fp32 matrix, one full 1 KiB row (K=256) per instruction
+__global__ void rd_fullrow(const float* X, float* out, long M, int K) {
+    const int lane = threadIdx.x & 63; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    f4 acc = {0, 0, 0, 0};
+    for (int i = 0; i < 64; ++i) { long r = w * 64 + i; if (r < M) for (int c = lane; c < K / 4; c += 64) acc += *(const f4*)(X + r * K + 4 * c); }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = acc[0];
+}
+// (b) same rows, but in 256-byte column windows (4 rows x 256 B per instruction), window after window
+__global__ void rd_window(const float* X, float* out, long M, int K) {
+    const int lane = threadIdx.x & 63; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    f4 acc = {0, 0, 0, 0};
+    for (int q = 0; q < K / 64; ++q)
+        for (int i = 0; i < 16; ++i) { long r = w * 64 + i * 4 + (lane >> 4); if (r < M) acc += *(const f4*)(X + r * K + q * 64 + 4 * (lane & 15)); }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = acc[0];
+}
+// (c) a lane owns a row (token) and writes 16-byte pieces: per instruction 32 rows x 32 B (tlin epilogue shape)
+__global__ void wr_lane_rows(float* Y, long M, int N) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    for (int t = 0; t < 2; ++t) { long r = w * 64 + t * 32 + c; if (r >= M) continue;
+        for (int nt = 0; nt < N / 32; ++nt) for (int g = 0; g < 4; ++g) { f4 v = {1.f * nt, 2, 3, 4}; *(f4*)(Y + r * N + nt * 32 + 8 * g + 4 * h) = v; } }
+}
+// (d) full-row contiguous writes (1 KiB per instruction)
+__global__ void wr_fullrow(float* Y, long M, int N) {
+    const int lane = threadIdx.x & 63; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    for (int i = 0; i < 64; ++i) { long r = w * 64 + i; if (r < M) for (int c = lane; c < N / 4; c += 64) { f4 v = {1.f * i, 2, 3, 4}; *(f4*)(Y + r * N + 4 * c) = v; } }
+}
+// (e) tile-GEMM style epilogue: per instruction 2 x 128 B row segments (32 lanes x 4 B), 64 instructions
+__global__ void wr_tile4B(float* Y, long M, int N) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long tiles_n = N / 32; const long tm = w / tiles_n, tn = w % tiles_n;   // a wave owns a 32x32 tile
+    for (int i = 0; i < 16; ++i) { long r = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h; if (r < M) Y[r * N + tn * 32 + c] = 1.f * i; }
+}
+template <typename F> float timeit(F f) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize(); hipEventRecord(a); for (int i = 0; i < 10; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms / 10 * 1e3f;
+}
+int main() {
+    const long M = 197376; float *X, *Y, *out;
+    CK(hipMalloc(&X, M * 1024 * 4)); CK(hipMalloc(&Y, M * 1024 * 4)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(X, 0, M * 1024 * 4));
+    const long waves = (M + 63) / 64; const int blocks = (int)((waves + 3) / 4);
+    for (int K : {256, 512, 1024}) {
+        float t = timeit([&] { rd_fullrow<<<blocks, 256>>>(X, out, M, K); });
+        printf("read  full rows      K=%4d: %7.1f us %6.2f TB/s\n", K, t, M * K * 4.0 / t / 1e6);
+        t = timeit([&] { rd_window<<<blocks, 256>>>(X, out, M, K); });
+        printf("read  256B windows   K=%4d: %7.1f us %6.2f TB/s\n", K, t, M * K * 4.0 / t / 1e6);
+    }
+    for (int N : {256, 768}) {
+        float t = timeit([&] { wr_lane_rows<<<blocks, 256>>>(Y, M, N); });
+        printf("write lane-owns-row  N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 4.0 / t / 1e6);
+        t = timeit([&] { wr_fullrow<<<blocks, 256>>>(Y, M, N); });
+        printf("write full rows      N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 4.0 / t / 1e6);
+        const long w2 = (M / 32) * (N / 32); const int b2 = (int)((w2 + 3) / 4);
+        t = timeit([&] { wr_tile4B<<<b2, 256>>>(Y, M, N); });
+        printf("write 32x32 tile 4B  N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 4.0 / t / 1e6);
+    }
+    return 0;
+}
