@@ -61,6 +61,7 @@ SYMBOLS = {
     "gg_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_flash": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_tlin": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_sqx": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_reset_optimizer_steps": (C.c_int, [C.c_void_p]),
     "gg_get_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

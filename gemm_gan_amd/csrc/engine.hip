@@ -75,7 +75,8 @@ struct CondActs {
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     uint8_t* mask;
     LayerActs L[MAXL];
-    float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out;
+    float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar;
+    bool sqx = false;
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
 };
@@ -127,6 +128,8 @@ struct gg_engine {
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
     float *s_delta;
     int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
+    int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
+    float *s_dqt;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
     float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
@@ -226,6 +229,7 @@ void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
     c.t2i_P = a.take<float>(RB * nh * S);
     c.t2i_ctx = a.take<float>(RB * E);
     c.t2i_out = a.take<float>(RB * E);
+    c.t2i_xbar = a.take<float>(RB * nh * E);
     c.i2t_q = a.take<float>(RB * E);
     c.i2t_kv = a.take<float>(RB * T * 2 * E);
     c.i2t_P = a.take<float>(RB * nh * T);
@@ -282,6 +286,7 @@ size_t carve(gg_engine* e, void* base) {
     e->s_dmod = a.take<float>(B * P * Dp);
     e->s_dgb = a.take<float>(B * 2 * Dp);
     e->s_delta = a.take<float>(Rb * nh * S);
+    e->s_dqt = a.take<float>(Rb * nh * E);
     return a.off + 256;
 }
 
@@ -532,13 +537,19 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     }
     // T2I: query = text CLS embedding, keys = values = encoder output (R:218)
     GG_TRY(lin_fwd(c, tok, (long)T * E, w + n.t2i.inw, E, w + n.t2i.inb, a.t2i_q, E, (int)RB, E, E));
-    {
-        TlinP t;
-        t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, n.t2i.inw + (long)E * E); t.ldw = E; t.bias = w + n.t2i.inb + E;
-        t.Y = a.t2i_kv; t.ldy = 2 * E; t.N = 2 * E; t.K = E;
-        TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + n.t2i.inw + (long)E * E, E, w + n.t2i.inb + E, a.t2i_kv, 2 * E, (int)(RB * S), 2 * E, E)));
+    a.sqx = e->sqx_on && sqx_supported(S, E, nh);
+    if (a.sqx) {
+        // K / V projections folded into the query side: one fused per-sample kernel streams the encoder output
+        KL(sqx_attn_fwd(a.t2i_q, x_in, w + n.t2i.inw, w + n.t2i.inb, a.mask, B, a.t2i_P, a.t2i_xbar, a.t2i_ctx, (int)RB, S, E, nh, c.st));
+    } else {
+        {
+            TlinP t;
+            t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, n.t2i.inw + (long)E * E); t.ldw = E; t.bias = w + n.t2i.inb + E;
+            t.Y = a.t2i_kv; t.ldy = 2 * E; t.N = 2 * E; t.K = E;
+            TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + n.t2i.inw + (long)E * E, E, w + n.t2i.inb + E, a.t2i_kv, 2 * E, (int)(RB * S), 2 * E, E)));
+        }
+        KL(k_sq_attn_fwd(a.t2i_q, a.t2i_kv, a.mask, B, a.t2i_P, a.t2i_ctx, (int)RB, S, E, nh, c.st));
     }
-    KL(k_sq_attn_fwd(a.t2i_q, a.t2i_kv, a.mask, B, a.t2i_P, a.t2i_ctx, (int)RB, S, E, nh, c.st));
     GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
     // I2T: query = that vector, keys = values = encoded text tokens (R:220)
     GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
@@ -582,17 +593,34 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     GG_TRY(lin_bwd_weight(c, e->s_dp, E, a.t2i_ctx, E, g + n.t2i.ow, E, (int)RB, E, E));
     KL(k_colsum(e->s_dp, RB, E, E, g + n.t2i.ob, c.st));
     GG_TRY(lin_bwd_data(c, e->s_dp, E, w + n.t2i.ow, E, e->s_tmpE, E, (int)RB, E, E));
-    KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
-    GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
-    KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
-    GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
-    GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
-    KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
-    {   // denc = dkv Wkv : reduction over the 2E projected features, W^T = columns E..3E of in_proj^T
-        TlinP t;
-        t.X = e->s_dkv; t.ldx = 2 * E; t.M = RB * S; t.W = WTB(n, n.t2i.inw + E); t.ldw = 3 * E;
-        t.Y = e->sdx; t.ldy = E; t.N = E; t.K = 2 * E;
-        TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E)));
+    if (a.sqx) {
+        KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq, e->s_dqt, (int)RB, S, E, nh, c.st));
+        {   // dWk_h += q_h (x) dqt_h  and  dWv_h += dctx_h (x) xbar_h, summed over the batch (per-head small GEMMs)
+            GemmP p;
+            p.M = dh; p.N = E; p.K = (int)RB; p.layA = LAY_KS; p.layB = LAY_KS; p.lda = E; p.ldb = (long)nh * E; p.ldc = E;
+            p.batch = nh; p.batch_inner = 1; p.sAo = dh; p.sBo = E; p.sCo = (long)dh * E; p.accumulate = 1;
+            p.A = a.t2i_q; p.B = e->s_dqt; p.C = g + n.t2i.inw + (long)E * E;
+            GG_TRY(run_gemm(c, p));
+            p.A = e->s_tmpE; p.B = a.t2i_xbar; p.C = g + n.t2i.inw + 2L * E * E;
+            GG_TRY(run_gemm(c, p));
+        }
+        KL(k_colsum(e->s_tmpE, RB, E, E, g + n.t2i.inb + 2 * E, c.st));          // d(bv) = sum dctx ; d(bk) == 0
+        GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+        KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
+        GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+    } else {
+        KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
+        GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+        KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
+        GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+        GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
+        KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
+        {   // denc = dkv Wkv : reduction over the 2E projected features, W^T = columns E..3E of in_proj^T
+            TlinP t;
+            t.X = e->s_dkv; t.ldx = 2 * E; t.M = RB * S; t.W = WTB(n, n.t2i.inw + E); t.ldw = 3 * E;
+            t.Y = e->sdx; t.ldy = E; t.N = E; t.K = 2 * E;
+            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E)));
+        }
     }
     // ---- encoder layers, last to first ---------------------------------------------------------------
     float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
@@ -1037,6 +1065,11 @@ int gg_set_flash(gg_engine* e, int on) {
 int gg_set_tlin(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->tlin_on = on != 0;
+    return 0;
+}
+int gg_set_sqx(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->sqx_on = on != 0;
     return 0;
 }
 int gg_set_seed(gg_engine* e, uint64_t seed) {

@@ -128,6 +128,15 @@ int tlin(const TlinP& p, hipStream_t st);
 struct ShadowEntry { long off; int rows, cols; };
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 
+// single-query attention over un-projected keys/values (sqattn.hip) ------------------------------------------------
+bool sqx_supported(int S, int E, int nh);
+// q [N,E] projected query; x [N,S,E]; Win [3E,E], bin [3E] packed in-proj; probs [N,nh,S], xbar [N,nh,E], ctx [N,E]
+int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* bin, const uint8_t* mask, int mask_B, float* probs,
+                 float* xbar, float* ctx, int N, int S, int E, int nh, hipStream_t st);
+// dctx [N,E] -> dx [N,S,E], dq [N,E], dqt [N,nh,E]  (dWk_h += q_h (x) dqt_h and dWv_h += dctx_h (x) xbar_h are the caller's GEMMs)
+int sqx_attn_bwd(const float* dctx, const float* q, const float* x, const float* Win, const float* probs, float* dx, float* dq,
+                 float* dqt, int N, int S, int E, int nh, hipStream_t st);
+
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
 enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };

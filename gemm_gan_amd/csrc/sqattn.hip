@@ -1,0 +1,249 @@
+// Single-query multi-head attention over a long key/value sequence WITHOUT projecting the keys and values
+// (R:218-219: patch2text_attention(query = text CLS embedding, key = value = encoder output)).
+//
+// With ONE query per sample the K / V projections of torch's MultiheadAttention fold into the query side:
+//     score[h,s] = scale * q_h . (Wk_h x_s + bk_h) = scale * (Wk_h^T q_h) . x_s + const(h)      (const drops out of softmax)
+//     ctx_h      = sum_s p[h,s] (Wv_h x_s + bv_h) = Wv_h (sum_s p[h,s] x_s) + bv_h               (sum_s p = 1)
+// so instead of a [N*S, E] x [E, 2E] projection (and its two backward GEMMs) the kernel streams the raw
+// encoder output x [S, E] of its sample twice (second pass from L2) and does 2*nh dot products per row:
+// S*E*2*nh MACs instead of S*E*2*E - a 32x reduction at E = 256, nh = 4 - and the op becomes a pure
+// HBM stream of x (forward) / x + dx (backward).  Exact same function as the reference, fp32 throughout.
+//
+// One workgroup per sample n.  Notation: qt_h = Wk_h^T q_h [E], xbar_h = sum_s p[h,s] x_s [E].
+#include "kernels.h"
+
+namespace gg {
+
+namespace {
+constexpr int TPB = 256;
+constexpr int MAXS = 2048;
+constexpr int MAXH = 8;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// out[h][e] = sum_d vec[h*dh + d] * W[(row0 + h*dh + d) * E + e]      (W^T applied per head)   -> LDS [nh][E]
+__device__ __forceinline__ void headwise_WT_vec(float* out, const float* __restrict__ W, int row0, const float* vec, int E, int nh,
+                                                int tid) {
+    const int dh = E / nh;
+    for (int i = tid; i < nh * E; i += TPB) {
+        const int h = i / E, e = i % E;
+        float acc = 0.f;
+        for (int d = 0; d < dh; ++d) acc += vec[h * dh + d] * W[(long)(row0 + h * dh + d) * E + e];
+        out[i] = acc;
+    }
+}
+// out[h*dh + d] = sum_e W[(row0 + h*dh + d) * E + e] * in[h][e]  (+ bias)                      (W applied per head)
+__device__ __forceinline__ void headwise_W_vec(float* out, const float* __restrict__ W, int row0, const float* in, const float* bias,
+                                               int E, int nh, int tid) {
+    const int dh = E / nh;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < E; j += TPB / 64) {      // one wave per output feature: coalesced read of a weight row
+        const int h = j / dh;
+        float acc = 0.f;
+        for (int e = lane; e < E; e += 64) acc += W[(long)(row0 + j) * E + e] * in[h * E + e];
+        acc = wave_sum(acc);
+        if (lane == 0) out[j] = acc + (bias ? bias[j] : 0.f);
+    }
+}
+
+// scores / generic "dot every row of x with nh vectors":  sc[h][s] = alpha * v_h . x_s
+__device__ __forceinline__ void rows_dot(float* sc, const float* __restrict__ x, const float* vecs /*LDS [nh][E]*/, int S, int E, int nh,
+                                         float alpha, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int s = wave; s < S; s += TPB / 64) {
+        float acc[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) acc[h] = 0.f;
+        for (int e = lane * 4; e < E; e += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)s * E + e);
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h)
+                if (h < nh) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(vecs + h * E + e);
+                    acc[h] += xv[0] * qv[0] + xv[1] * qv[1] + xv[2] * qv[2] + xv[3] * qv[3];
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+            if (h < nh) {
+                const float r = wave_sum(acc[h]);
+                if (lane == 0) sc[h * MAXS + s] = r * alpha;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward:  q [N,E] (projected query incl. bias), x [N,S,E], Win [3E,E] / bin [3E] (packed in-proj), mask
+//           -> probs [N,nh,S], xbar [N,nh,E] (saved for backward), ctx [N,E]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void sqx_fwd_kernel(const float* __restrict__ q, const float* __restrict__ x,
+                                                       const float* __restrict__ Win, const float* __restrict__ bin,
+                                                       const uint8_t* __restrict__ mask, int mask_B, float* __restrict__ probs,
+                                                       float* __restrict__ xbar, float* __restrict__ ctx, int S, int E, int nh) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;                 // [E]
+    float* qt = qs + E;             // [nh][E]
+    float* xb = qt + nh * E;        // [nh][E]
+    float* sc = xb + nh * E;        // [nh][MAXS]
+    const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* xn = x + (long)n * S * E;
+    const float scale = rsqrtf((float)(E / nh));
+    for (int i = tid; i < E; i += TPB) qs[i] = q[(long)n * E + i];
+    __syncthreads();
+    headwise_WT_vec(qt, Win, E, qs, E, nh, tid);          // Wk = rows E..2E of in_proj
+    __syncthreads();
+    rows_dot(sc, xn, qt, S, E, nh, scale, tid);
+    __syncthreads();
+    for (int h = wave; h < nh; h += TPB / 64) {           // masked softmax over the keys, one wave per head
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) {
+            float v = sc[h * MAXS + s];
+            if (mask && mask[(long)(n % mask_B) * S + s]) v = -INFINITY;
+            sc[h * MAXS + s] = v;
+            m = fmaxf(m, v);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float e = __expf(sc[h * MAXS + s] - m);
+            sc[h * MAXS + s] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int s = lane; s < S; s += 64) {
+            const float p = sc[h * MAXS + s] * inv;
+            sc[h * MAXS + s] = p;
+            probs[((long)n * nh + h) * S + s] = p;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += TPB) {                 // xbar_h = sum_s p[h,s] x_s : thread owns a feature column,
+        float acc[MAXH];                                 // x re-read once from L2, coalesced over e
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) acc[h] = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float xv = xn[(long)s * E + e];
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h)
+                if (h < nh) acc[h] += sc[h * MAXS + s] * xv;
+        }
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+            if (h < nh) {
+                xb[h * E + e] = acc[h];
+                xbar[((long)n * nh + h) * E + e] = acc[h];
+            }
+    }
+    __syncthreads();
+    headwise_W_vec(ctx + (long)n * E, Win, 2 * E, xb, bin + 2 * E, E, nh, tid);     // Wv = rows 2E..3E
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: dctx [N,E] -> dx [N,S,E] (overwritten), dq [N,E] (grad of the projected query), and the per-sample
+//           factors of the weight gradients: dqt [N,nh,E] (dWk_h += q_h (x) dqt_h), xbar saved (dWv_h += dctx_h (x) xbar_h)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ q,
+                                                       const float* __restrict__ x, const float* __restrict__ Win,
+                                                       const float* __restrict__ probs, float* __restrict__ dx,
+                                                       float* __restrict__ dq, float* __restrict__ dqt_out, int S, int E, int nh) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;                 // [E]   projected query
+    float* dc = qs + E;             // [E]   dctx
+    float* qt = dc + E;             // [nh][E]
+    float* dxb = qt + nh * E;       // [nh][E]  d(xbar)
+    float* dqt = dxb + nh * E;      // [nh][E]
+    float* pr = dqt + nh * E;       // [nh][MAXS] probabilities
+    float* ds = pr + nh * MAXS;     // [nh][MAXS] d(score) (already times scale)
+    const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* xn = x + (long)n * S * E;
+    float* dxn = dx + (long)n * S * E;
+    const float scale = rsqrtf((float)(E / nh));
+    for (int i = tid; i < E; i += TPB) {
+        qs[i] = q[(long)n * E + i];
+        dc[i] = dctx[(long)n * E + i];
+    }
+    for (int i = tid; i < nh * S; i += TPB) pr[(i / S) * MAXS + (i % S)] = probs[(long)n * nh * S + i];
+    __syncthreads();
+    headwise_WT_vec(qt, Win, E, qs, E, nh, tid);           // qt_h  = Wk_h^T q_h
+    headwise_WT_vec(dxb, Win, 2 * E, dc, E, nh, tid);      // dxbar_h = Wv_h^T dctx_h
+    __syncthreads();
+    rows_dot(ds, xn, dxb, S, E, nh, 1.f, tid);             // dp[h,s] = dxbar_h . x_s
+    __syncthreads();
+    for (int h = wave; h < nh; h += TPB / 64) {            // softmax backward (masked keys have p = 0)
+        float dot = 0.f;
+        for (int s = lane; s < S; s += 64) dot += ds[h * MAXS + s] * pr[h * MAXS + s];
+        dot = wave_sum(dot);
+        for (int s = lane; s < S; s += 64) ds[h * MAXS + s] = pr[h * MAXS + s] * (ds[h * MAXS + s] - dot) * scale;
+    }
+    __syncthreads();
+    // dx_s = sum_h p[h,s] dxbar_h + ds[h,s] qt_h ;  dqt_h = sum_s ds[h,s] x_s      (thread owns feature columns)
+    for (int e = tid; e < E; e += TPB) {
+        float a_dxb[MAXH], a_qt[MAXH], a_dqt[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) {
+            a_dxb[h] = h < nh ? dxb[h * E + e] : 0.f;
+            a_qt[h] = h < nh ? qt[h * E + e] : 0.f;
+            a_dqt[h] = 0.f;
+        }
+        for (int s = 0; s < S; ++s) {
+            const float xv = xn[(long)s * E + e];
+            float o = 0.f;
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h)
+                if (h < nh) {
+                    const float g = ds[h * MAXS + s];
+                    o += pr[h * MAXS + s] * a_dxb[h] + g * a_qt[h];
+                    a_dqt[h] += g * xv;
+                }
+            dxn[(long)s * E + e] = o;
+        }
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+            if (h < nh) {
+                dqt[h * E + e] = a_dqt[h];
+                dqt_out[((long)n * nh + h) * E + e] = a_dqt[h];
+            }
+    }
+    __syncthreads();
+    headwise_W_vec(dq + (long)n * E, Win, E, dqt, nullptr, E, nh, tid);     // dq_h = Wk_h dqt_h
+}
+
+size_t fwd_smem(int E, int nh) { return sizeof(float) * ((size_t)E + 2 * (size_t)nh * E + (size_t)nh * MAXS); }
+size_t bwd_smem(int E, int nh) { return sizeof(float) * (2 * (size_t)E + 3 * (size_t)nh * E + 2 * (size_t)nh * MAXS); }
+}  // namespace
+
+bool sqx_supported(int S, int E, int nh) {
+    return nh >= 1 && nh <= MAXH && E % nh == 0 && E % 4 == 0 && S <= MAXS && bwd_smem(E, nh) <= 160 * 1024;
+}
+
+int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* bin, const uint8_t* mask, int mask_B, float* probs,
+                 float* xbar, float* ctx, int N, int S, int E, int nh, hipStream_t st) {
+    GG_REQUIRE(sqx_supported(S, E, nh), "sqx attention: unsupported shape");
+    const size_t sm = fwd_smem(E, nh);
+    GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sqx_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(sqx_fwd_kernel, dim3(N), dim3(TPB), sm, st, q, x, Win, bin, mask, mask_B > 0 ? mask_B : N, probs, xbar, ctx, S, E, nh);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sqx_attn_bwd(const float* dctx, const float* q, const float* x, const float* Win, const float* probs, float* dx, float* dq,
+                 float* dqt, int N, int S, int E, int nh, hipStream_t st) {
+    GG_REQUIRE(sqx_supported(S, E, nh), "sqx attention: unsupported shape");
+    const size_t sm = bwd_smem(E, nh);
+    GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sqx_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(sqx_bwd_kernel, dim3(N), dim3(TPB), sm, st, dctx, q, x, Win, probs, dx, dq, dqt, S, E, nh);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gg

@@ -155,6 +155,9 @@ class Engine:
     def set_flash(self, on: bool):
         L.check(self.lib.gg_set_flash(self.h, int(on)))
 
+    def set_sqx(self, on: bool):
+        L.check(self.lib.gg_set_sqx(self.h, int(on)))
+
     def set_tlin(self, on: bool):
         L.check(self.lib.gg_set_tlin(self.h, int(on)))
 

@@ -271,8 +271,8 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     for k in a["gstate"]:
         from gpu_util import diag as _d
         _d(f"      dG {k:60s} cos {_cos(a['gstate'][k], b['gstate'][k]):.6f}")
-    ck.check("critic losses", a["losses"][:3], b["losses"][:3])
-    ck.check("generator loss", a["gl"][3:4], b["gl"][3:4])
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=1e-2)
+    ck.check("generator loss", a["gl"][3:4], b["gl"][3:4], tol=1e-2)
     from gpu_util import diag
     cd, cg = _cos(a["g"], b["g"]), _cos(a["gg"], b["gg"])
     diag(f"   flat gradient cosine tlin vs generic: critic {cd:.6f} generator {cg:.6f}")
