@@ -357,141 +357,160 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward, dK / dV: keys on the lanes.  One workgroup of 3 waves per (sample, head); in round r wave w
-// owns key tile 3r+w and keeps its dK^T, dV^T [dh x 32 keys] in accumulators while the workgroup
-// streams every query tile (Q, dO staged row-major AND transposed in LDS, double buffered).
+// backward, dK / dV: keys on the lanes.  One WAVE per (sample, head, 32-key tile) - no workgroup barriers.
+// The wave keeps K, V fragments of its key tile and the dK^T, dV^T [dh x 32 keys] accumulators in
+// registers and walks all query tiles.  Per query tile it loads its 32 rows of Q and dO once: the packed
+// bf16 registers ARE the row-major A fragments of S = Q K^T and dP = dO V^T; the same 16-byte pieces go to a
+// wave-private LDS slab from which the TRANSPOSED A fragments of dV^T += dO^T P and dK^T += Q^T dS come
+// back through ds_read_b64_tr_b16 (hardware transpose read: lane 4q+p of a 16-lane group supplies row q,
+// columns 4p..4p+3 of a 4x16 block and receives column (lane & 15), rows 0..3).
 // ------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int ld, int col0, int s2, int lane) {
+    const int i = lane & 15, grp = lane >> 4;
+    const int hh = grp >> 1, colhalf = grp & 1;
+    const __bf16* p0 = img + (16 * s2 + 4 * hh + (i >> 2)) * ld + col0 + 16 * colhalf + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * ld));
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
 template <int DH>
-__global__ __launch_bounds__(192) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                            const float* __restrict__ lse2, const float* __restrict__ delta,
                                                            const uint8_t* __restrict__ mask, int mask_B,
-                                                           float* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
-    constexpr int LDR = DH + 8;      // row-major tile [32][DH+8]
-    constexpr int LDC = 32 + 8;      // transposed tile [DH][32+8]
+                                                           float* __restrict__ dqkv, int S, int E, int nh, DropKey drop,
+                                                           long total_items) {
+    constexpr int LDR = DH + 8;      // row-major tile [32][DH+8] bf16
     constexpr int DT = (DH + 31) / 32;
     constexpr int KS = DH / 16;
-    __shared__ __attribute__((aligned(16))) __bf16 Qr[2][32 * LDR];
-    __shared__ __attribute__((aligned(16))) __bf16 Dr[2][32 * LDR];
-    __shared__ __attribute__((aligned(16))) __bf16 Qc[2][DH * LDC];
-    __shared__ __attribute__((aligned(16))) __bf16 Dc[2][DH * LDC];
-    __shared__ float Ls[2][32], Dl[2][32];
+    __shared__ __attribute__((aligned(16))) __bf16 Qr[4][32 * LDR];
+    __shared__ __attribute__((aligned(16))) __bf16 Dr[4][32 * LDR];
+    __shared__ float Ls[4][32], Dl[4][32];
 
     const int Sp = (S + 31) / 32 * 32;
-    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int nqt = Sp / 32, nkt = Sp / 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= total_items) return;                   // whole wave leaves: nothing below synchronises across waves
+    const int kt = (int)(item % nkt);
+    const long nhid = item / nkt;                      // n * nh + head
+    const int n = (int)(nhid / nh), hd = (int)(nhid % nh);
     const long ld = 3L * E;
     const float* base = qkv + (long)n * S * ld + hd * DH;
     const float* dbase = dctx + (long)n * S * E + hd * DH;
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-    const int nqt = Sp / 32, nkt = Sp / 32;
-    const int rounds = (nkt + 2) / 3;
 
-    auto stage = [&](int buf, int qt) {
-        const float* qsrc = base + (long)qt * 32 * ld;
-        const float* dsrc = dbase + (long)qt * 32 * E;
-        const int rows = min(32, S - qt * 32);
-        stage_rows<DH>(Qr[buf], qsrc, ld, rows, 32, tid, 192);
-        stage_rows<DH>(Dr[buf], dsrc, E, rows, 32, tid, 192);
-        stage_transposed<DH>(Qc[buf], qsrc, ld, rows, 32, tid, 192);
-        stage_transposed<DH>(Dc[buf], dsrc, E, rows, 32, tid, 192);
-        if (tid < 32) {
-            const int q = qt * 32 + tid;
-            Ls[buf][tid] = q < S ? lse2[(long)blockIdx.x * S + q] : 0.f;
-            Dl[buf][tid] = q < S ? delta[(long)blockIdx.x * S + q] : 0.f;
+    const int key = kt * 32 + c;
+    const bool kvalid = key < S && !(mask && mask[(long)(n % mask_B) * S + key]);
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < S) {
+            const float* kp = base + (long)key * ld + E + 16 * s + 8 * h;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(kp), hi = *reinterpret_cast<const f32x4*>(kp + 4);
+            const f32x4 vlo = *reinterpret_cast<const f32x4*>(kp + E), vhi = *reinterpret_cast<const f32x4*>(kp + E + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = vlo[j]; w[4 + j] = vhi[j]; }
         }
-    };
+        kf[s] = frag_from_f32(v);
+        vf[s] = frag_from_f32(w);
+    }
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
 
-    for (int r = 0; r < rounds; ++r) {
-        const int kt = 3 * r + wave;
-        const bool active = kt < nkt;
-        const int key = kt * 32 + c;
-        const bool kvalid = active && key < S && !(mask && mask[(long)(n % mask_B) * S + key]);
-        bf16x8 kf[KS], vf[KS];
+    __bf16* qimg = Qr[wave];
+    __bf16* dimg = Dr[wave];
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q = qt * 32 + c;
+        bf16x8 qa[KS], da[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (active && key < S) {
-                const float* kp = base + (long)key * ld + E + 16 * s + 8 * h;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(kp), hi = *reinterpret_cast<const f32x4*>(kp + 4);
-                const f32x4 vlo = *reinterpret_cast<const f32x4*>(kp + E), vhi = *reinterpret_cast<const f32x4*>(kp + E + 4);
+            if (q < S) {
+                const float* qp = base + (long)q * ld + 16 * s + 8 * h;
+                const float* dp = dbase + (long)q * E + 16 * s + 8 * h;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(qp), hi = *reinterpret_cast<const f32x4*>(qp + 4);
+                const f32x4 dlo = *reinterpret_cast<const f32x4*>(dp), dhi = *reinterpret_cast<const f32x4*>(dp + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = vlo[j]; w[4 + j] = vhi[j]; }
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = dlo[j]; w[4 + j] = dhi[j]; }
             }
-            kf[s] = frag_from_f32(v);
-            vf[s] = frag_from_f32(w);
+            qa[s] = frag_from_f32(v);
+            da[s] = frag_from_f32(w);
+            *reinterpret_cast<bf16x8*>(qimg + c * LDR + 16 * s + 8 * h) = qa[s];
+            *reinterpret_cast<bf16x8*>(dimg + c * LDR + 16 * s + 8 * h) = da[s];
         }
-        f32x16 dK[DT], dV[DT];
+        if (h == 0) {
+            Ls[wave][c] = q < S ? lse2[nhid * S + q] : 0.f;
+            Dl[wave][c] = q < S ? delta[nhid * S + q] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        f32x16 s16, dp16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s], kf[s], s16, 0, 0, 0);
+            dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[s], vf[s], dp16, 0, 0, 0);
+        }
+        f32x16 pd16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, h);
+            const int qq = qt * 32 + row;
+            float pd = 0.f, ds = 0.f;
+            if (kvalid && qq < S) {
+                const float p = fast_exp2(s16[i] * sc - Ls[wave][row]);
+                const float kfac = drop.p > 0.f ? drop_factor(drop, ((uint64_t)nhid * S + (uint64_t)qq) * S + (uint64_t)key, ks) : 1.f;
+                pd = p * kfac;
+                ds = p * (dp16[i] * kfac - Dl[wave][row]) * scale;
+            }
+            pd16[i] = pd;
+            s16[i] = ds;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = frag_from_acc(pd16, s2);
+            const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 dof = frag_tr(dimg, LDR, dt * 32, s2, lane);
+                const bf16x8 qtf = frag_tr(qimg, LDR, dt * 32, s2, lane);
+                dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
+                dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (key < S) {
+        float* outk = dqkv + ((long)n * S + key) * ld + E + hd * DH;
+        float* outv = outk + E;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
-
-        __syncthreads();            // previous round's readers are done with both buffers
-        stage(0, 0);
-        __syncthreads();
-        for (int qt = 0; qt < nqt; ++qt) {
-            const int buf = qt & 1;
-            if (qt + 1 < nqt) stage(buf ^ 1, qt + 1);
-            if (active) {
-                f32x16 s16, dp16;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qr[buf] + c * LDR + 16 * s + 8 * h);
-                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(Dr[buf] + c * LDR + 16 * s + 8 * h);
-                    s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], s16, 0, 0, 0);
-                    dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp16, 0, 0, 0);
-                }
-                f32x16 pd16;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = acc_row(i, h);
-                    const int q = qt * 32 + row;
-                    float p = 0.f, pd = 0.f, ds = 0.f;
-                    if (kvalid && q < S) {
-                        p = fast_exp2(s16[i] * sc - Ls[buf][row]);
-                        const float kf_ = drop.p > 0.f ? drop_factor(drop, ((uint64_t)blockIdx.x * S + (uint64_t)q) * S + (uint64_t)key, ks) : 1.f;
-                        pd = p * kf_;
-                        ds = p * (dp16[i] * kf_ - Dl[buf][row]) * scale;
-                    }
-                    pd16[i] = pd;
-                    s16[i] = ds;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = frag_from_acc(pd16, s2);
-                    const bf16x8 sf = frag_from_acc(s16, s2);
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const bf16x8 dof = frag_transposed(Dc[buf], LDC, min(dt * 32 + c, DH - 1), 0, s2, h);
-                        const bf16x8 qtf = frag_transposed(Qc[buf], LDC, min(dt * 32 + c, DH - 1), 0, s2, h);
-                        dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
-                        dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 a = {dK[dt][4 * g], dK[dt][4 * g + 1], dK[dt][4 * g + 2], dK[dt][4 * g + 3]};
+                    f32x4 b = {dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2], dV[dt][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(outk + d) = a;
+                    *reinterpret_cast<f32x4*>(outv + d) = b;
                 }
             }
-            __syncthreads();
-        }
-        if (active && key < S) {
-            float* outk = dqkv + ((long)n * S + key) * ld + E + hd * DH;
-            float* outv = outk + E;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = dt * 32 + 8 * g + 4 * h;
-                    if (d < DH) {
-                        f32x4 a = {dK[dt][4 * g], dK[dt][4 * g + 1], dK[dt][4 * g + 2], dK[dt][4 * g + 3]};
-                        f32x4 b = {dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2], dV[dt][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(outk + d) = a;
-                        *reinterpret_cast<f32x4*>(outv + d) = b;
-                    }
-                }
-        }
     }
 }
 
@@ -544,11 +563,12 @@ int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const 
     const int dh = E / nh;
     const size_t sm = dq_smem(S, dh);
     const dim3 grid((unsigned)(N * nh));
+    const long items = N * nh * ((S + 31) / 32);       // one wave per (sample, head, key tile)
 #define GG_BWD(D)                                                                                                        \
     do {                                                                                                                 \
         GG_TRY(set_smem(&attn_bwd_dq_kernel<D>, sm));                                                                    \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, dim3(192), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items); \
     } while (0)
     if (dh == 64) GG_BWD(64);
     else if (dh == 32) GG_BWD(32);

@@ -16,7 +16,7 @@ namespace gg {
 
 namespace {
 constexpr int TPB = 256;
-constexpr int MAXS = 2048;
+constexpr int MAXS = 2048;      // capacity; LDS score arrays are strided by the padded actual length
 constexpr int MAXH = 8;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -56,8 +56,8 @@ __device__ __forceinline__ void headwise_W_vec(float* out, const float* __restri
 }
 
 // scores / generic "dot every row of x with nh vectors":  sc[h][s] = alpha * v_h . x_s
-__device__ __forceinline__ void rows_dot(float* sc, const float* __restrict__ x, const float* vecs /*LDS [nh][E]*/, int S, int E, int nh,
-                                         float alpha, int tid) {
+__device__ __forceinline__ void rows_dot(float* sc, int SS, const float* __restrict__ x, const float* vecs /*LDS [nh][E]*/, int S,
+                                         int E, int nh, float alpha, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     for (int s = wave; s < S; s += TPB / 64) {
         float acc[MAXH];
@@ -76,7 +76,7 @@ __device__ __forceinline__ void rows_dot(float* sc, const float* __restrict__ x,
         for (int h = 0; h < MAXH; ++h)
             if (h < nh) {
                 const float r = wave_sum(acc[h]);
-                if (lane == 0) sc[h * MAXS + s] = r * alpha;
+                if (lane == 0) sc[h * SS + s] = r * alpha;
             }
     }
 }
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(TPB) void sqx_fwd_kernel(const float* __restrict__ 
     float* qs = sm;                 // [E]
     float* qt = qs + E;             // [nh][E]
     float* xb = qt + nh * E;        // [nh][E]
-    float* sc = xb + nh * E;        // [nh][MAXS]
+    float* sc = xb + nh * E;        // [nh][SS]
+    const int SS = (S + 3) & ~3;
     const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* xn = x + (long)n * S * E;
     const float scale = rsqrtf((float)(E / nh));
@@ -101,28 +102,28 @@ __global__ __launch_bounds__(TPB) void sqx_fwd_kernel(const float* __restrict__ 
     __syncthreads();
     headwise_WT_vec(qt, Win, E, qs, E, nh, tid);          // Wk = rows E..2E of in_proj
     __syncthreads();
-    rows_dot(sc, xn, qt, S, E, nh, scale, tid);
+    rows_dot(sc, SS, xn, qt, S, E, nh, scale, tid);
     __syncthreads();
     for (int h = wave; h < nh; h += TPB / 64) {           // masked softmax over the keys, one wave per head
         float m = -INFINITY;
         for (int s = lane; s < S; s += 64) {
-            float v = sc[h * MAXS + s];
+            float v = sc[h * SS + s];
             if (mask && mask[(long)(n % mask_B) * S + s]) v = -INFINITY;
-            sc[h * MAXS + s] = v;
+            sc[h * SS + s] = v;
             m = fmaxf(m, v);
         }
         m = wave_max(m);
         float sum = 0.f;
         for (int s = lane; s < S; s += 64) {
-            const float e = __expf(sc[h * MAXS + s] - m);
-            sc[h * MAXS + s] = e;
+            const float e = __expf(sc[h * SS + s] - m);
+            sc[h * SS + s] = e;
             sum += e;
         }
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
         for (int s = lane; s < S; s += 64) {
-            const float p = sc[h * MAXS + s] * inv;
-            sc[h * MAXS + s] = p;
+            const float p = sc[h * SS + s] * inv;
+            sc[h * SS + s] = p;
             probs[((long)n * nh + h) * S + s] = p;
         }
     }
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(TPB) void sqx_fwd_kernel(const float* __restrict__ 
             const float xv = xn[(long)s * E + e];
 #pragma unroll
             for (int h = 0; h < MAXH; ++h)
-                if (h < nh) acc[h] += sc[h * MAXS + s] * xv;
+                if (h < nh) acc[h] += sc[h * SS + s] * xv;
         }
 #pragma unroll
         for (int h = 0; h < MAXH; ++h)
@@ -162,8 +163,9 @@ __global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ 
     float* qt = dc + E;             // [nh][E]
     float* dxb = qt + nh * E;       // [nh][E]  d(xbar)
     float* dqt = dxb + nh * E;      // [nh][E]
-    float* pr = dqt + nh * E;       // [nh][MAXS] probabilities
-    float* ds = pr + nh * MAXS;     // [nh][MAXS] d(score) (already times scale)
+    const int SS = (S + 3) & ~3;
+    float* pr = dqt + nh * E;       // [nh][SS] probabilities
+    float* ds = pr + nh * SS;       // [nh][SS] d(score) (already times scale)
     const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* xn = x + (long)n * S * E;
     float* dxn = dx + (long)n * S * E;
@@ -172,18 +174,18 @@ __global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ 
         qs[i] = q[(long)n * E + i];
         dc[i] = dctx[(long)n * E + i];
     }
-    for (int i = tid; i < nh * S; i += TPB) pr[(i / S) * MAXS + (i % S)] = probs[(long)n * nh * S + i];
+    for (int i = tid; i < nh * S; i += TPB) pr[(i / S) * SS + (i % S)] = probs[(long)n * nh * S + i];
     __syncthreads();
     headwise_WT_vec(qt, Win, E, qs, E, nh, tid);           // qt_h  = Wk_h^T q_h
     headwise_WT_vec(dxb, Win, 2 * E, dc, E, nh, tid);      // dxbar_h = Wv_h^T dctx_h
     __syncthreads();
-    rows_dot(ds, xn, dxb, S, E, nh, 1.f, tid);             // dp[h,s] = dxbar_h . x_s
+    rows_dot(ds, SS, xn, dxb, S, E, nh, 1.f, tid);             // dp[h,s] = dxbar_h . x_s
     __syncthreads();
     for (int h = wave; h < nh; h += TPB / 64) {            // softmax backward (masked keys have p = 0)
         float dot = 0.f;
-        for (int s = lane; s < S; s += 64) dot += ds[h * MAXS + s] * pr[h * MAXS + s];
+        for (int s = lane; s < S; s += 64) dot += ds[h * SS + s] * pr[h * SS + s];
         dot = wave_sum(dot);
-        for (int s = lane; s < S; s += 64) ds[h * MAXS + s] = pr[h * MAXS + s] * (ds[h * MAXS + s] - dot) * scale;
+        for (int s = lane; s < S; s += 64) ds[h * SS + s] = pr[h * SS + s] * (ds[h * SS + s] - dot) * scale;
     }
     __syncthreads();
     // dx_s = sum_h p[h,s] dxbar_h + ds[h,s] qt_h ;  dqt_h = sum_s ds[h,s] x_s      (thread owns feature columns)
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ 
 #pragma unroll
             for (int h = 0; h < MAXH; ++h)
                 if (h < nh) {
-                    const float g = ds[h * MAXS + s];
-                    o += pr[h * MAXS + s] * a_dxb[h] + g * a_qt[h];
+                    const float g = ds[h * SS + s];
+                    o += pr[h * SS + s] * a_dxb[h] + g * a_qt[h];
                     a_dqt[h] += g * xv;
                 }
             dxn[(long)s * E + e] = o;
@@ -218,18 +220,18 @@ __global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ 
     headwise_W_vec(dq + (long)n * E, Win, E, dqt, nullptr, E, nh, tid);     // dq_h = Wk_h dqt_h
 }
 
-size_t fwd_smem(int E, int nh) { return sizeof(float) * ((size_t)E + 2 * (size_t)nh * E + (size_t)nh * MAXS); }
-size_t bwd_smem(int E, int nh) { return sizeof(float) * (2 * (size_t)E + 3 * (size_t)nh * E + 2 * (size_t)nh * MAXS); }
+size_t fwd_smem(int S, int E, int nh) { return sizeof(float) * ((size_t)E + 2 * (size_t)nh * E + (size_t)nh * ((S + 3) & ~3)); }
+size_t bwd_smem(int S, int E, int nh) { return sizeof(float) * (2 * (size_t)E + 3 * (size_t)nh * E + 2 * (size_t)nh * ((S + 3) & ~3)); }
 }  // namespace
 
 bool sqx_supported(int S, int E, int nh) {
-    return nh >= 1 && nh <= MAXH && E % nh == 0 && E % 4 == 0 && S <= MAXS && bwd_smem(E, nh) <= 160 * 1024;
+    return nh >= 1 && nh <= MAXH && E % nh == 0 && E % 4 == 0 && S <= MAXS && bwd_smem(S, E, nh) <= 160 * 1024;
 }
 
 int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* bin, const uint8_t* mask, int mask_B, float* probs,
                  float* xbar, float* ctx, int N, int S, int E, int nh, hipStream_t st) {
     GG_REQUIRE(sqx_supported(S, E, nh), "sqx attention: unsupported shape");
-    const size_t sm = fwd_smem(E, nh);
+    const size_t sm = fwd_smem(S, E, nh);
     GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sqx_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL(sqx_fwd_kernel, dim3(N), dim3(TPB), sm, st, q, x, Win, bin, mask, mask_B > 0 ? mask_B : N, probs, xbar, ctx, S, E, nh);
     GG_CHECK_HIP(hipGetLastError());
@@ -239,7 +241,7 @@ int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* 
 int sqx_attn_bwd(const float* dctx, const float* q, const float* x, const float* Win, const float* probs, float* dx, float* dq,
                  float* dqt, int N, int S, int E, int nh, hipStream_t st) {
     GG_REQUIRE(sqx_supported(S, E, nh), "sqx attention: unsupported shape");
-    const size_t sm = bwd_smem(E, nh);
+    const size_t sm = bwd_smem(S, E, nh);
     GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sqx_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL(sqx_bwd_kernel, dim3(N), dim3(TPB), sm, st, dctx, q, x, Win, probs, dx, dq, dqt, S, E, nh);
     GG_CHECK_HIP(hipGetLastError());
