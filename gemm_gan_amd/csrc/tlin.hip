@@ -14,7 +14,7 @@
 //     (bias, ReLU, dropout, activation-mask, += , residual add and LayerNorm over the features) is
 //     in-lane arithmetic plus one cross-half shuffle, and each lane stores 16-byte pieces of its own row.
 // Two instantiation families:
-//   stream   (NT_RES = 0): K <= 256 resident, any N streamed 32 features at a time, TOK = 64.
+//   stream   (NT_RES = 0): K <= 256 resident, any N streamed 32 features at a time, TOK = 32.
 //   resident (NT_RES = N/32 <= 8): all N accumulators resident, K streamed in slices of 256, TOK = 32;
 //                                  enables the fused residual + LayerNorm epilogue (N = E).
 #include "kernels.h"
@@ -49,7 +49,7 @@ constexpr float LN_EPS = 1e-5f;
 // KSL: length of the K slice kept register-resident (64 | 128 | 256); K must be a multiple of KSL so that
 // every MFMA chain below is straight-line code with compile-time fragment indices.
 template <int TOK, int NT_RES, int KSL>
-__global__ __launch_bounds__(256) void tlin_kernel(const TlinP p) {
+__global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const TlinP p) {
     constexpr int TT = TOK / 32;                       // 32-token fragment sets per wave
     constexpr int NACC = NT_RES > 0 ? NT_RES : 1;
     constexpr int WLD = KSL + 8;                       // bf16 per LDS row of a weight chunk
@@ -158,11 +158,17 @@ __global__ __launch_bounds__(256) void tlin_kernel(const TlinP p) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) acc[nt][t][i] = 0.f;
                 }
+                // weight fragments are fetched four k-steps at a time so the LDS latency is paid once per group
 #pragma unroll
-                for (int s = 0; s < KSL / 16; ++s) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * s + 8 * h]);
+                for (int s4 = 0; s4 < KSL / 64; ++s4) {
+                    bf16x8 wf[4];
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[t][s], acc[nt][t], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * (4 * s4 + u) + 8 * h]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < TT; ++t)
+                            acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[t][4 * s4 + u], acc[nt][t], 0, 0, 0);
                 }
                 if (more) store_chunk(buf ^ 1);
                 __syncthreads();
@@ -178,10 +184,15 @@ __global__ __launch_bounds__(256) void tlin_kernel(const TlinP p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[0][t][i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < KSL / 16; ++s) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * s + 8 * h]);
+                for (int s4 = 0; s4 < KSL / 64; ++s4) {
+                    bf16x8 wf[4];
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[t][s], acc[0][t], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * (4 * s4 + u) + 8 * h]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < TT; ++t)
+                            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[t][4 * s4 + u], acc[0][t], 0, 0, 0);
                 }
                 // ---- streamed epilogue: 32 features x TOK tokens -------------------------------------------
 #pragma unroll
@@ -333,9 +344,9 @@ bool tlin_supported(const TlinP& p) {
 int tlin(const TlinP& p, hipStream_t st) {
     GG_REQUIRE(tlin_supported(p), "tlin: unsupported shape / alignment");
     if (!needs_resident(p)) {
-        if (p.K == 256) return launch<64, 0, 256>(p, st);
-        if (p.K == 128) return launch<64, 0, 128>(p, st);
-        return launch<64, 0, 64>(p, st);
+        if (p.K == 256) return launch<32, 0, 256>(p, st);
+        if (p.K == 128) return launch<32, 0, 128>(p, st);
+        return launch<32, 0, 64>(p, st);
     }
     if (p.N == 256) return launch<32, 8, 256>(p, st);
     if (p.N == 128) return launch<32, 4, 128>(p, st);
