@@ -198,30 +198,37 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     const long tok = tok0 + t * 32 + c;
-                    if (tok < p.M) {
-                        const long yrow = p.y_row_group ? tok + tok / p.y_row_group + 1 : tok;
+                    const bool valid = tok < p.M;
+                    const long tokc = valid ? tok : last_tok;
+                    const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
+                    float* yb = p.Y + yrow * p.ldy + nt * 32 + 4 * h;
+                    const float* mb = p.mask_ref ? p.mask_ref + tokc * p.ldref + nt * 32 + 4 * h : nullptr;
+                    f32x4 mm[4], yy[4], bb[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int n = nt * 32 + 8 * g + 4 * h;
-                            f32x4 v = {acc[0][t][4 * g], acc[0][t][4 * g + 1], acc[0][t][4 * g + 2], acc[0][t][4 * g + 3]};
-                            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                            if (p.act_relu) {
+                    for (int g = 0; g < 4; ++g) {
+                        mm[g] = mb ? *reinterpret_cast<const f32x4*>(mb + 8 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        yy[g] = p.accumulate ? *reinterpret_cast<const f32x4*>(yb + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        bb[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                            }
-                            if (p.drop.p > 0.f) {
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nt * 32 + 8 * g + 4 * h;
+                        f32x4 v = {acc[0][t][4 * g], acc[0][t][4 * g + 1], acc[0][t][4 * g + 2], acc[0][t][4 * g + 3]};
+                        v += bb[g];
+                        if (p.act_relu) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tok * p.drop_ld + n + j, ksd);
-                            }
-                            if (p.mask_ref) {
-                                const f32x4 r = *reinterpret_cast<const f32x4*>(p.mask_ref + tok * p.ldref + n);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = r[j] > 0.f ? v[j] * p.mask_scale : 0.f;
-                            }
-                            float* yp = p.Y + yrow * p.ldy + n;
-                            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
-                            *reinterpret_cast<f32x4*>(yp) = v;
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         }
+                        if (p.drop.p > 0.f) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tokc * p.drop_ld + n + j, ksd);
+                        }
+                        if (mb) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = mm[g][j] > 0.f ? v[j] * p.mask_scale : 0.f;
+                        }
+                        v += yy[g];
+                        if (valid) *reinterpret_cast<f32x4*>(yb + 8 * g) = v;
                     }
                 }
                 if (more) store_chunk(buf ^ 1);
@@ -236,25 +243,32 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
         constexpr int t = 0;                         // TOK == 32 in resident mode
         const long tok = tok0 + c;
         const bool valid = tok < p.M;
-        const long yrow = p.y_row_group ? tok + tok / p.y_row_group + 1 : tok;
+        const long tokc = valid ? tok : last_tok;        // clamped row: loads are unconditional (batched, no exec branches)
+        const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
+        const float* resp = p.res ? p.res + (tokc % p.res_rows) * p.ldres : nullptr;
+        float* yb = p.Y + yrow * p.ldy;
         float sum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT_RES; ++nt) {
+            f32x4 rr[4], yy[4], bb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                // issue the tile's loads together
+                const int n = nt * 32 + 8 * g + 4 * h;
+                rr[g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                yy[g] = p.accumulate ? *reinterpret_cast<const f32x4*>(yb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bb[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nt * 32 + 8 * g + 4 * h;
                 f32x4 v = {acc[nt][t][4 * g], acc[nt][t][4 * g + 1], acc[nt][t][4 * g + 2], acc[nt][t][4 * g + 3]};
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.drop.p > 0.f && valid) {
+                v += bb[g];
+                if (p.drop.p > 0.f) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tok * p.drop_ld + n + j, ksd);
+                    for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tokc * p.drop_ld + n + j, ksd);
                 }
-                if (valid) {
-                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (tok % p.res_rows) * p.ldres + n);
-                    float* yp = p.Y + yrow * p.ldy + n;
-                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
-                    *reinterpret_cast<f32x4*>(yp) = v;
-                }
+                v += rr[g] + yy[g];
+                if (valid) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[nt][t][4 * g + j] = v[j];
