@@ -56,44 +56,99 @@ __device__ __forceinline__ bf16x8 frag_from_acc(const f32x16& a, int s2) {   // 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 constexpr float LOG2E = 1.4426950408889634f;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// 8 consecutive elements at element offset `off` of a fp32 (IOB = false) or bf16 (IOB = true) tensor, as an MFMA fragment
+template <bool IOB>
+__device__ __forceinline__ bf16x8 load_frag8(const void* base, long off) {
+    if constexpr (IOB) {
+        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(base) + off);
+    } else {
+        const float* p = reinterpret_cast<const float*>(base) + off;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+        u32x4 w = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+        return __builtin_bit_cast(bf16x8, w);
+    }
+}
+// the same 8 elements as fp32 values
+template <bool IOB>
+__device__ __forceinline__ void load_f32x8(const void* base, long off, float (&v)[8]) {
+    if constexpr (IOB) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = __builtin_bit_cast(float, w[j] << 16);
+            v[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+        }
+    } else {
+        const float* p = reinterpret_cast<const float*>(base) + off;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    }
+}
+// 4 consecutive fp32 results to a fp32 / bf16 tensor
+template <bool IOB>
+__device__ __forceinline__ void store4(void* base, long off, f32x4 v) {
+    if constexpr (IOB) {
+        u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(base) + off) = w;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    }
+}
 // raw v_exp_f32 (2^x): inputs here are <= 0 or -inf; flush-to-zero of tiny results is harmless for softmax
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- LDS staging -------------------------------------------------------------------------------------
 // row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled
-template <int DH>
-__device__ __forceinline__ void stage_rows(__bf16* img, const float* __restrict__ X, long ldx, int S, int Sp, int tid, int nthreads) {
+template <int DH, bool IOB>
+__device__ __forceinline__ void stage_rows(__bf16* img, const void* X, long xoff, long ldx, int S, int Sp, int tid, int nthreads) {
     constexpr int LD = DH + 8;
     const int nchunk = Sp * (DH / 8);
     for (int c = tid; c < nchunk; c += nthreads) {
         const int row = c / (DH / 8), c8 = c % (DH / 8);
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (row < S) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 8 * c8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 8 * c8 + 4);
-            w = u32x4{pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
-        }
-        *reinterpret_cast<u32x4*>(img + row * LD + 8 * c8) = w;
+        bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < S) w = load_frag8<IOB>(X, xoff + (long)row * ldx + 8 * c8);
+        *reinterpret_cast<bf16x8*>(img + row * LD + 8 * c8) = w;
     }
 }
 // transposed image  img[d][row] (ld = Sp+8 bf16) of X[row, col0 + d]
-template <int DH>
-__device__ __forceinline__ void stage_transposed(__bf16* img, const float* __restrict__ X, long ldx, int S, int Sp, int tid, int nthreads) {
+template <int DH, bool IOB>
+__device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, long xoff, long ldx, int S, int Sp, int tid, int nthreads) {
     const int LD = Sp + 8;
     const int nunit = (Sp / 8) * (DH / 4);
     for (int u = tid; u < nunit; u += nthreads) {
         const int r8 = u / (DH / 4), d4 = u % (DH / 4);
-        f32x4 v[8];
+        if constexpr (IOB) {
+            const __bf16* Xb = reinterpret_cast<const __bf16*>(X) + xoff;
+            s16x4_t v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = 8 * r8 + j;
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < S) v[j] = *reinterpret_cast<const f32x4*>(X + (long)row * ldx + 4 * d4);
-        }
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * r8 + j;
+                v[j] = s16x4_t{0, 0, 0, 0};
+                if (row < S) v[j] = *reinterpret_cast<const s16x4_t*>(Xb + (long)row * ldx + 4 * d4);
+            }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            u32x4 w = {pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q]), pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};
-            *reinterpret_cast<u32x4*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+            for (int q = 0; q < 4; ++q) {
+                bf16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = v[j][q];
+                *reinterpret_cast<bf16x8*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+            }
+        } else {
+            const float* Xf = reinterpret_cast<const float*>(X) + xoff;
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * r8 + j;
+                v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < S) v[j] = *reinterpret_cast<const f32x4*>(Xf + (long)row * ldx + 4 * d4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x4 w = {pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q]), pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};
+                *reinterpret_cast<u32x4*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+            }
         }
     }
 }
@@ -111,9 +166,9 @@ __device__ __forceinline__ bf16x8 frag_transposed(const __bf16* img, int ld, int
 // forward: one workgroup (4 waves) per (sample, head); K row-major + V transposed resident in LDS; each
 // wave walks query tiles of 32 rows with an online softmax over key tiles of 32.
 // ------------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
-                                                       int mask_B, float* __restrict__ ctx, float* __restrict__ lse2,
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                       int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
                                                        int S, int E, int nh, DropKey drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
@@ -129,29 +184,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
-    const float* base = qkv + (long)n * S * ld + hd * DH;
-    stage_rows<DH>(Ks, base + E, ld, S, Sp, tid, 256);
-    stage_transposed<DH>(Vt, base + 2 * E, ld, S, Sp, tid, 256);
+    const long base = (long)n * S * ld + hd * DH;          // element offset of this (sample, head) inside qkv
+    stage_rows<DH, IOB>(Ks, qkv, base + E, ld, S, Sp, tid, 256);
+    stage_transposed<DH, IOB>(Vt, qkv, base + 2 * E, ld, S, Sp, tid, 256);
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
 
-    const float sc = rsqrtf((float)DH) * LOG2E;
+    const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     const int nqt = Sp / 32, nkt = Sp / 32;
     for (int qt = wave; qt < nqt; qt += 4) {
         const int q = qt * 32 + c;
         bf16x8 qf[KS];
+        const int qc = min(q, S - 1);                  // rows past the end re-read the last query: never stored
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (q < S) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(base + (long)q * ld + 16 * s + 8 * h);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(base + (long)q * ld + 16 * s + 8 * h + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; }
-            }
-            qf[s] = frag_from_f32(v);
-        }
+        for (int s = 0; s < KS; ++s) qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
         float m = -INFINITY, l = 0.f;
         f32x16 O[DT];
 #pragma unroll
@@ -172,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kt * 32 + acc_row(i, h);
-                if (Ms[key]) s16[i] = -INFINITY;
+                s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
                 mt = fmaxf(mt, s16[i]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -209,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         if (q < S) {
             const float inv = ks / l;
-            float* out = ctx + ((long)n * S + q) * E + hd * DH;
+            const long out = ((long)n * S + q) * E + hd * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                     const int d = dt * 32 + 8 * g + 4 * h;
                     if (d < DH) {
                         f32x4 v = {O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv};
-                        *reinterpret_cast<f32x4*>(out + d) = v;
+                        store4<IOB>(ctx, out + d, v);
                     }
                 }
             if (h == 0) lse2[(long)blockIdx.x * S + q] = m + log2f(l);
@@ -245,12 +292,12 @@ __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __r
 // ------------------------------------------------------------------------------------------------------
 // backward, dQ: same orientation as forward.  LDS: K row-major, V row-major, K transposed.
 // ------------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                          const float* __restrict__ dctx,
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict__ qkv, const void* __restrict__ ctx,
+                                                          const void* __restrict__ dctx,
                                                           const float* __restrict__ lse2, float* __restrict__ delta,
                                                           const uint8_t* __restrict__ mask, int mask_B,
-                                                          float* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
+                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -266,10 +313,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
-    const float* base = qkv + (long)n * S * ld + hd * DH;
-    stage_rows<DH>(Ks, base + E, ld, S, Sp, tid, 256);
-    stage_rows<DH>(Vs, base + 2 * E, ld, S, Sp, tid, 256);
-    stage_transposed<DH>(Kt, base + E, ld, S, Sp, tid, 256);
+    const long base = (long)n * S * ld + hd * DH;
+    stage_rows<DH, IOB>(Ks, qkv, base + E, ld, S, Sp, tid, 256);
+    stage_rows<DH, IOB>(Vs, qkv, base + 2 * E, ld, S, Sp, tid, 256);
+    stage_transposed<DH, IOB>(Kt, qkv, base + E, ld, S, Sp, tid, 256);
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
 
@@ -282,25 +329,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         bf16x8 qf[KS], df[KS];
         float L2 = 0.f, dl = 0.f;
         if (q < S) L2 = lse2[(long)blockIdx.x * S + q];
+        const int qc = min(q, S - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (q < S) {
-                const float* qp = base + (long)q * ld + 16 * s + 8 * h;
-                const long off = ((long)n * S + q) * E + hd * DH + 16 * s + 8 * h;
-                const float* dp = dctx + off;
-                const float* op = ctx + off;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(qp), hi = *reinterpret_cast<const f32x4*>(qp + 4);
-                const f32x4 dlo = *reinterpret_cast<const f32x4*>(dp), dhi = *reinterpret_cast<const f32x4*>(dp + 4);
-                const f32x4 olo = *reinterpret_cast<const f32x4*>(op), ohi = *reinterpret_cast<const f32x4*>(op + 4);
+            const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+            qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+            df[s] = load_frag8<IOB>(dctx, off);
+            float dv[8], ov[8];
+            load_f32x8<IOB>(dctx, off, dv);
+            load_f32x8<IOB>(ctx, off, ov);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = lo[j] * sc; v[4 + j] = hi[j] * sc; w[j] = dlo[j]; w[4 + j] = dhi[j];
-                    dl += dlo[j] * olo[j] + dhi[j] * ohi[j];
-                }
-            }
-            qf[s] = frag_from_f32(v);
-            df[s] = frag_from_f32(w);
+            for (int j = 0; j < 8; ++j) dl += dv[j] * ov[j];
         }
         // delta[q] = sum_d dO*O : this lane-half covered half of the head dim, the other half the rest
         dl += __shfl_xor(dl, 32, 64);
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kt * 32 + acc_row(i, h);
-                const float p = Ms[key] ? 0.f : fast_exp2(s16[i] - L2);
+                const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
                 float dp = dp16[i];
                 if (drop.p > 0.f) dp *= drop_factor(drop, rowbase + (uint64_t)key, ks);
                 s16[i] = p * (dp - dl) * scale;
@@ -341,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
             }
         }
         if (q < S) {
-            float* out = dqkv + ((long)n * S + q) * ld + hd * DH;
+            const long out = ((long)n * S + q) * ld + hd * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                     const int d = dt * 32 + 8 * g + 4 * h;
                     if (d < DH) {
                         f32x4 v = {dQ[dt][4 * g], dQ[dt][4 * g + 1], dQ[dt][4 * g + 2], dQ[dt][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(out + d) = v;
+                        store4<IOB>(dqkv, out + d, v);
                     }
                 }
         }
@@ -379,11 +418,11 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int ld, int col0, i
     return r;
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restrict__ qkv, const void* __restrict__ dctx,
                                                            const float* __restrict__ lse2, const float* __restrict__ delta,
                                                            const uint8_t* __restrict__ mask, int mask_B,
-                                                           float* __restrict__ dqkv, int S, int E, int nh, DropKey drop,
+                                                           void* __restrict__ dqkv, int S, int E, int nh, DropKey drop,
                                                            long total_items) {
     constexpr int LDR = DH + 8;      // row-major tile [32][DH+8] bf16
     constexpr int DT = (DH + 31) / 32;
@@ -402,8 +441,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     const long nhid = item / nkt;                      // n * nh + head
     const int n = (int)(nhid / nh), hd = (int)(nhid % nh);
     const long ld = 3L * E;
-    const float* base = qkv + (long)n * S * ld + hd * DH;
-    const float* dbase = dctx + (long)n * S * E + hd * DH;
+    const long base = (long)n * S * ld + hd * DH;
+    const long dbase = (long)n * S * E + hd * DH;
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
@@ -411,18 +450,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     const int key = kt * 32 + c;
     const bool kvalid = key < S && !(mask && mask[(long)(n % mask_B) * S + key]);
     bf16x8 kf[KS], vf[KS];
+    const int keyc = min(key, S - 1);                  // keys past the end re-read the last key: masked below, never stored
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < S) {
-            const float* kp = base + (long)key * ld + E + 16 * s + 8 * h;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(kp), hi = *reinterpret_cast<const f32x4*>(kp + 4);
-            const f32x4 vlo = *reinterpret_cast<const f32x4*>(kp + E), vhi = *reinterpret_cast<const f32x4*>(kp + E + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = vlo[j]; w[4 + j] = vhi[j]; }
-        }
-        kf[s] = frag_from_f32(v);
-        vf[s] = frag_from_f32(w);
+        kf[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + E + 16 * s + 8 * h);
+        vf[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + 2 * E + 16 * s + 8 * h);
     }
     f32x16 dK[DT], dV[DT];
 #pragma unroll
@@ -435,19 +467,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     for (int qt = 0; qt < nqt; ++qt) {
         const int q = qt * 32 + c;
         bf16x8 qa[KS], da[KS];
+        const int qc = min(q, S - 1);                  // rows past the end: finite duplicates, zeroed by (qq < S) below
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (q < S) {
-                const float* qp = base + (long)q * ld + 16 * s + 8 * h;
-                const float* dp = dbase + (long)q * E + 16 * s + 8 * h;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(qp), hi = *reinterpret_cast<const f32x4*>(qp + 4);
-                const f32x4 dlo = *reinterpret_cast<const f32x4*>(dp), dhi = *reinterpret_cast<const f32x4*>(dp + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; w[j] = dlo[j]; w[4 + j] = dhi[j]; }
-            }
-            qa[s] = frag_from_f32(v);
-            da[s] = frag_from_f32(w);
+            qa[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+            da[s] = load_frag8<IOB>(dctx, dbase + (long)qc * E + 16 * s + 8 * h);
             *reinterpret_cast<bf16x8*>(qimg + c * LDR + 16 * s + 8 * h) = qa[s];
             *reinterpret_cast<bf16x8*>(dimg + c * LDR + 16 * s + 8 * h) = da[s];
         }
@@ -497,8 +521,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         __builtin_amdgcn_wave_barrier();
     }
     if (key < S) {
-        float* outk = dqkv + ((long)n * S + key) * ld + E + hd * DH;
-        float* outv = outk + E;
+        const long outk = ((long)n * S + key) * ld + E + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -507,8 +530,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                 if (d < DH) {
                     f32x4 a = {dK[dt][4 * g], dK[dt][4 * g + 1], dK[dt][4 * g + 2], dK[dt][4 * g + 3]};
                     f32x4 b = {dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2], dV[dt][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(outk + d) = a;
-                    *reinterpret_cast<f32x4*>(outv + d) = b;
+                    store4<IOB>(dqkv, outk + d, a);
+                    store4<IOB>(dqkv, outk + E + d, b);
                 }
             }
     }
@@ -538,41 +561,53 @@ bool flash_attn_supported(int S, int E, int nh) {
     return dq_smem(S, dh) <= 160 * 1024 && fwd_smem(S, dh) <= 160 * 1024;
 }
 
-int flash_attn_fwd(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
-                   DropKey drop, hipStream_t st) {
+int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
+                   DropKey drop, int io_bf16, hipStream_t st) {
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
     const size_t sm = fwd_smem(S, dh);
     const dim3 grid((unsigned)(N * nh));
-#define GG_FWD(D)                                                                                          \
-    do {                                                                                                   \
-        GG_TRY(set_smem(&attn_fwd_kernel<D>, sm));                                                         \
-        hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop); \
+#define GG_FWD(D, B)                                                                                          \
+    do {                                                                                                      \
+        GG_TRY(set_smem(&attn_fwd_kernel<D, B>, sm));                                                         \
+        hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop); \
     } while (0)
-    if (dh == 64) GG_FWD(64);
-    else if (dh == 32) GG_FWD(32);
-    else GG_FWD(16);
+    if (io_bf16) {
+        if (dh == 64) GG_FWD(64, true);
+        else if (dh == 32) GG_FWD(32, true);
+        else GG_FWD(16, true);
+    } else {
+        if (dh == 64) GG_FWD(64, false);
+        else if (dh == 32) GG_FWD(32, false);
+        else GG_FWD(16, false);
+    }
 #undef GG_FWD
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st) {
+int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st) {
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
     const size_t sm = dq_smem(S, dh);
     const dim3 grid((unsigned)(N * nh));
     const long items = N * nh * ((S + 31) / 32);       // one wave per (sample, head, key tile)
-#define GG_BWD(D)                                                                                                        \
-    do {                                                                                                                 \
-        GG_TRY(set_smem(&attn_bwd_dq_kernel<D>, sm));                                                                    \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items); \
+#define GG_BWD(D, B)                                                                                                        \
+    do {                                                                                                                    \
+        GG_TRY(set_smem(&attn_bwd_dq_kernel<D, B>, sm));                                                                    \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items); \
     } while (0)
-    if (dh == 64) GG_BWD(64);
-    else if (dh == 32) GG_BWD(32);
-    else GG_BWD(16);
+    if (io_bf16) {
+        if (dh == 64) GG_BWD(64, true);
+        else if (dh == 32) GG_BWD(32, true);
+        else GG_BWD(16, true);
+    } else {
+        if (dh == 64) GG_BWD(64, false);
+        else if (dh == 32) GG_BWD(32, false);
+        else GG_BWD(16, false);
+    }
 #undef GG_BWD
     GG_CHECK_HIP(hipGetLastError());
     return 0;

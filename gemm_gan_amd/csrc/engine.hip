@@ -72,6 +72,7 @@ struct CondActs {
     uint32_t call = 0;
     float drop = 0.f;
     bool flash = false;
+    bool bst = false;          // qkv / ctx / h (and their gradients) stored as bf16 in this pass
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     uint8_t* mask;
     LayerActs L[MAXL];
@@ -128,6 +129,7 @@ struct gg_engine {
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
     float *s_delta;
     int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
+    int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
@@ -363,10 +365,11 @@ int lin_bwd_data(Ctx& c, const float* dY, long ldy, const float* W, long ldw, fl
 }
 
 // dW[N,K] += dY[M,N]^T @ X[M,K]     (reduction over the M rows, split over workgroups, fp32 atomics)
-int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K) {
+int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K,
+                   int dy_bf16 = 0, int x_bf16 = 0) {
     GemmP p;
     p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
-    p.layA = LAY_KS; p.layB = LAY_KS;
+    p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = dy_bf16; p.b_bf16 = x_bf16;
     const long tiles = tiles_of(N, K);
     long sk = std::max<long>(1, std::min<long>((M + 255) / 256, (512 + tiles - 1) / tiles));
     p.splitk = (int)sk;
@@ -424,6 +427,13 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (_t == 0) { fallback; }            \
     } while (0)
 
+#define TLIN_MUST(p_)                                                                           \
+    do {                                                                                        \
+        const int _t = try_tlin(c, p_);                                                         \
+        if (_t < 0) return -1;                                                                  \
+        if (_t == 0) { set_error("bf16-stored operand reached a shape tlin cannot run"); return -2; } \
+    } while (0)
+
 DropKey dkey(gg_engine* e, const CondActs& a, int net, int layer, int site) {
     return make_drop_key(a.drop, e->seed, (uint32_t)(net * 1000 + layer * 10 + site), a.call);
 }
@@ -468,18 +478,23 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     const float scale = 1.f / sqrtf((float)dh);
     const bool use_flash = e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(S, E, nh);
     a.flash = use_flash;
+    // bf16 storage of the tensors that are only ever read as bf16 MFMA operands: every producer / consumer
+    // must be a tlin / flash kernel, which holds for E in {64,128,256} (see tlin_supported)
+    const bool bst = e->bstore_on && use_flash && use_tlin(e) && (E == 64 || E == 128 || E == 256);
+    a.bst = bst;
     for (int l = 0; l < e->nl; ++l) {
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
         {
             TlinP t;
             t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
-            t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E;
-            TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
+            t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E; t.y_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (use_flash) {
-            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, c.st));
+            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st));
         } else {
             {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
                 GemmP p;
@@ -507,8 +522,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.X = L.ctx; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.ow); t.ldw = E; t.bias = w + lp.sa.ob;
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
             t.res = x_in; t.ldres = E; t.res_rows = RB * S;
-            t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1;
-            TLIN_OR(t, {
+            t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
                 KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
             });
@@ -517,7 +533,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             TlinP t;
             t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
             t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
-            TLIN_OR(t, {
+            t.y_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
                 if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
             });
@@ -527,8 +545,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
             t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
             t.res = L.x1; t.ldres = E; t.res_rows = RB * S;
-            t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2;
-            TLIN_OR(t, {
+            t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
                 KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
             });
@@ -576,6 +595,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const float* enc = a.L[e->nl - 1].x2;
     const float drop = a.drop;
     const float ks = drop > 0.f ? 1.f / (1.f - drop) : 1.f;
+    const int bst = a.bst ? 1 : 0;
 
     // ---- I2T backward: t = out_proj(ctx); scores over text tokens; q from p -----------------------
     GG_TRY(lin_bwd_weight(c, dc, E, a.i2t_ctx, E, g + n.i2t.ow, E, (int)RB, E, E));
@@ -630,40 +650,44 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 ? a.xrep : a.x0);
         // LN2
         KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
-                           dkey(e, a, n.role, l, 3), c.st));
+                           dkey(e, a, n.role, l, 3), c.st, bst));
         // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))   (db2 = column sums of df: fused above)
-        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F));
+        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F, bst, bst));
         {   // dhpre = (df W2) * [h > 0] / (1-p) : the stored post-dropout h gates both ReLU and the kept-mask
             TlinP t;
             t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.l2w); t.ldw = E;
             t.Y = e->sdh; t.ldy = F; t.N = F; t.K = E; t.mask_ref = L.h; t.ldref = F; t.mask_scale = ks;
-            TLIN_OR(t, {
+            t.x_bf16 = bst; t.y_bf16 = bst; t.mask_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, {
                 GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.l2w, F, e->sdh, F, (int)(RB * S), E, F));
                 KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));
             });
         }
-        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E));
-        KL(k_colsum(e->sdh, RB * S, F, F, g + lp.l1b, c.st));
+        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0));
+        KL(k_colsum(e->sdh, RB * S, F, F, g + lp.l1b, c.st, bst));
         {   // dx1 = dr2 + dhpre W1
             TlinP t;
             t.X = e->sdh; t.ldx = F; t.M = RB * S; t.W = WTB(n, lp.l1w); t.ldw = F;
-            t.Y = e->sdr; t.ldy = E; t.N = E; t.K = F; t.accumulate = 1;
-            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1)));
+            t.Y = e->sdr; t.ldy = E; t.N = E; t.K = F; t.accumulate = 1; t.x_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1)));
         }
         // LN1
         KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
-                           dkey(e, a, n.role, l, 1), c.st));
+                           dkey(e, a, n.role, l, 1), c.st, bst));
         // self attention out-proj   (d(out_proj.bias) fused above)
-        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E));
+        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
         {
             TlinP t;
             t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.sa.ow); t.ldw = E;
-            t.Y = e->sdctx; t.ldy = E; t.N = E; t.K = E;
-            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
+            t.Y = e->sdctx; t.ldy = E; t.N = E; t.K = E; t.x_bf16 = bst; t.y_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (a.flash) {
-            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, c.st));
+            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st));
             c.e->launches += 2;
         } else {
             const float* Pd = L.P;
@@ -707,13 +731,14 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 GG_TRY(run_gemm(c, p));
             }
         }
-        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E));
-        KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st));
+        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0));
+        KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st, bst));
         {   // dx_in = dr1 + dqkv Win
             TlinP t;
             t.X = e->sdqkv; t.ldx = 3 * E; t.M = RB * S; t.W = WTB(n, lp.sa.inw); t.ldw = 3 * E;
-            t.Y = dx; t.ldy = E; t.N = E; t.K = 3 * E; t.accumulate = 1;
-            TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
+            t.Y = dx; t.ldy = E; t.N = E; t.K = 3 * E; t.accumulate = 1; t.x_bf16 = bst;
+            if (bst) TLIN_MUST(t);
+            else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
         }
     }
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
@@ -1065,6 +1090,21 @@ int gg_set_flash(gg_engine* e, int on) {
 int gg_set_tlin(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->tlin_on = on != 0;
+    return 0;
+}
+int gg_set_bstore(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->bstore_on = on != 0;
+    return 0;
+}
+int gg_debug_buffer_is_bf16(gg_engine* e, const char* name) {
+    if (!e || !name) return -1;
+    std::string s(name);
+    if (s.size() > 5 && s[1] == '.' && (s[0] == 'G' || s[0] == 'D') && s[2] == 'L') {
+        const CondActs& a = s[0] == 'G' ? e->actsG : e->actsD;
+        const std::string k = s.substr(5);
+        if (a.bst && (k == "qkv" || k == "ctx" || k == "h")) return 1;
+    }
     return 0;
 }
 int gg_set_sqx(gg_engine* e, int on) {

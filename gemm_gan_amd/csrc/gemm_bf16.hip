@@ -36,6 +36,24 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // ---- global -> registers: 8 float4 per thread per operand ------------------------------------------
 // LAY_KC: slot i = chunk (row = f>>3, c8 = f&7), f = tid + 256*(i>>1), half (i&1): k = k0 + 8*c8 + 4*(i&1)
 // LAY_KS: slot j = k row  k0 + 8*(tid>>5) + j, rows row0 + 4*(tid&31) .. +3
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// bf16-stored K-strided operand (weight-gradient products of bf16 branch gradients / activations): 8-byte loads of
+// 4 adjacent rows at one k, expanded exactly to fp32 so the staging below is shared with the fp32 path
+__device__ __forceinline__ void load_tile_ks_bf16(const __bf16* __restrict__ base, long ld, int rows_total, int row0, int k0,
+                                                   int kend, f32x4 (&r)[8], int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int gk = k0 + 8 * (tid >> 5) + i, gr = row0 + 4 * (tid & 31);
+        if (gk < kend && gr < rows_total) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(base + (long)gk * ld + gr);
+            v = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                      __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+        }
+        r[i] = v;
+    }
+}
+
 template <int LAY>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long ld, int rows_total, int row0, int k0,
                                           int kend, bool vec, f32x4 (&r)[8], int tid) {
@@ -116,7 +134,7 @@ __device__ __forceinline__ void store_tile(__bf16* tile, const f32x4 (&r)[8], in
     }
 }
 
-template <int LA, int LB>
+template <int LA, int LB, bool AB = false, bool BB = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, const Flags fl) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_bf16[];
     __bf16* As = smem_bf16;
@@ -149,6 +167,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
     const float* A = p.A + zo * p.sAo + zi * p.sAi;
     const float* B = p.B + zo * p.sBo + zi * p.sBi;
     float* C = p.C + zo * p.sCo + zi * p.sCi;
+    // bf16-stored operands: p.A / p.B point at bf16 data, offsets are in elements
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + zo * p.sAo + zi * p.sAi;
+    const __bf16* Bb = reinterpret_cast<const __bf16*>(p.B) + zo * p.sBo + zi * p.sBi;
 
     const int kbeg = sk * fl.kchunk;
     const int kend = min(p.K, kbeg + fl.kchunk);
@@ -157,6 +178,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    auto loadA = [&](int k0, f32x4 (&ra)[8]) {
+        if constexpr (AB) load_tile_ks_bf16(Ab, p.lda, p.M, m0, k0, kend, ra, tid);
+        else load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
+    };
+    auto loadB = [&](int k0, f32x4 (&rb)[8]) {
+        if constexpr (BB) load_tile_ks_bf16(Bb, p.ldb, p.N, n0, k0, kend, rb, tid);
+        else load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -168,9 +197,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
 
     f32x4 ra[8], rb[8];
     if (nkt > 0) {
-        load_tile<LA>(A, p.lda, p.M, m0, kbeg, kend, fl.vecA, ra, tid);
+        loadA(kbeg, ra);
         if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, kbeg, kend, fl.vecFilm, ra, tid);
-        load_tile<LB>(B, p.ldb, p.N, n0, kbeg, kend, fl.vecB, rb, tid);
+        loadB(kbeg, rb);
         store_tile<LA>(As, ra, tid);
         store_tile<LB>(Bs, rb, tid);
     }
@@ -181,9 +210,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
         const bool more = (kt + 1 < nkt);
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
+            loadA(k0, ra);
             if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, k0, kend, fl.vecFilm, ra, tid);
-            load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
+            loadB(k0, rb);
         }
         const __bf16* at = As + cur * TILE_ELEMS;
         const __bf16* bt = Bs + cur * TILE_ELEMS;
@@ -244,15 +273,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
 
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <int LA, int LB>
+template <int LA, int LB, bool AB = false, bool BB = false>
 int launch(const GemmP& p, const Flags& fl, dim3 grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<LA, LB>),
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<LA, LB, AB, BB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), grid, dim3(NTHREADS), SMEM_BYTES, st, p, fl);
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB, AB, BB>), grid, dim3(NTHREADS), SMEM_BYTES, st, p, fl);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -277,6 +306,14 @@ int gemm_bf16(const GemmP& p, hipStream_t st) {
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     GG_REQUIRE(tiles <= 2147483647L, "grid.x overflow");
     dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.splitk));
+    if (p.a_bf16 || p.b_bf16) {
+        GG_REQUIRE(p.layA == LAY_KS && p.layB == LAY_KS, "bf16-stored operands are supported for (K-strided, K-strided) products only");
+        GG_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.M % 4 == 0 && p.N % 4 == 0 && (reinterpret_cast<uintptr_t>(p.A) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(p.B) & 7) == 0 && strA && strB, "bf16-stored operands need 4-element alignment");
+        if (p.a_bf16 && p.b_bf16) return launch<LAY_KS, LAY_KS, true, true>(p, fl, grid, st);
+        if (p.a_bf16) return launch<LAY_KS, LAY_KS, true, false>(p, fl, grid, st);
+        return launch<LAY_KS, LAY_KS, false, true>(p, fl, grid, st);
+    }
     if (p.layA == LAY_KC && p.layB == LAY_KC) return launch<LAY_KC, LAY_KC>(p, fl, grid, st);
     if (p.layA == LAY_KC && p.layB == LAY_KS) return launch<LAY_KC, LAY_KS>(p, fl, grid, st);
     if (p.layA == LAY_KS && p.layB == LAY_KC) return launch<LAY_KS, LAY_KC>(p, fl, grid, st);

@@ -50,6 +50,7 @@ struct GemmP {
     int M = 0, N = 0, K = 0;
     long lda = 0, ldb = 0, ldc = 0;
     int layA = LAY_KC, layB = LAY_KC;
+    int a_bf16 = 0, b_bf16 = 0;          // gemm_bf16 only, (LAY_KS, LAY_KS) only: operand stored as bf16 (lda/ldb/strides in elements)
     int batch = 1, batch_inner = 1;
     long sAo = 0, sAi = 0, sBo = 0, sBi = 0, sCo = 0, sCi = 0;
     int splitk = 1;             // >1 => partial sums are atomically added into C (epilogue must be linear)

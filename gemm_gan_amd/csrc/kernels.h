@@ -49,10 +49,11 @@ int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g,
 // dbias (may be null) += column sums of that masked branch gradient (= bias gradient of the Linear
 // that produced the residual branch), saving a separate pass over the tensor.
 int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr,
-                    float* dres_out, float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st);
+                    void* dres_out, float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st,
+                    int dres_bf16 = 0);
 
 // out[n] += sum_rows X[r, n]
-int k_colsum(const float* X, long rows, int N, long ld, float* out, hipStream_t st);
+int k_colsum(const void* X, long rows, int N, long ld, float* out, hipStream_t st, int x_bf16 = 0);
 // out[n] += sum_rows X[r,n] * (ref[r,n] > 0 ? 1 : slope)
 int k_colsum_masked(const float* X, const float* ref, long rows, int N, float slope, float* out, hipStream_t st);
 // y *= (ref > 0 ? 1 : slope) * scale   (activation backward using the POST-activation value)
@@ -99,25 +100,26 @@ int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_wei
 
 // fused self-attention (attention.hip): bf16 MFMA, no [S,S] tensor in HBM -----------------------------------
 bool flash_attn_supported(int S, int E, int nh);
-// qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S]
-int flash_attn_fwd(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
-                   DropKey drop, hipStream_t st);
+// qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S].
+// io_bf16: qkv / ctx / dctx / dqkv are bf16 tensors (they only ever feed bf16 MFMA operands), else fp32.
+int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
+                   DropKey drop, int io_bf16, hipStream_t st);
 // dctx [N,S,E] -> dqkv [N,S,3E] (fully overwritten); delta [N,nh,S] scratch
-int flash_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st);
+int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st);
 
 // token-on-lane Linear (tlin.hip): Y[M,N] = epi(X[M,K] W[N,K]^T), bf16 MFMA, activations read once ---------------
 struct TlinP {
-    const float* X = nullptr; long ldx = 0; long M = 0;
+    const void* X = nullptr; long ldx = 0; long M = 0; int x_bf16 = 0;       // activations fp32 or bf16 (row stride in elements)
     const void* W = nullptr; long ldw = 0;          // bf16 [N][K] (row stride ldw elements)
     const float* bias = nullptr;
-    float* Y = nullptr; long ldy = 0;
+    void* Y = nullptr; long ldy = 0; int y_bf16 = 0;                          // output fp32 or (stream mode only) bf16
     int N = 0, K = 0;
     const float* film_g = nullptr; const float* film_b = nullptr; long film_ld = 0; int film_group = 0;   // X' = g*X + b
     int y_row_group = 0;                            // output row m -> m + m / group + 1
     int act_relu = 0;
     DropKey drop; long drop_ld = 0;                 // dropout of the Linear output, element index = token*drop_ld + n
-    const float* mask_ref = nullptr; long ldref = 0; float mask_scale = 1.f;   // y = ref > 0 ? y*scale : 0
+    const void* mask_ref = nullptr; long ldref = 0; float mask_scale = 1.f; int mask_bf16 = 0;   // y = ref > 0 ? y*scale : 0
     int accumulate = 0;                             // y += previous content
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;

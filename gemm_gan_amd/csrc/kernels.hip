@@ -383,10 +383,16 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r,
 }
 // float4 variant (E % 4 == 0): a lane owns 4 adjacent columns per 256-column group -> one 16-byte access per
 // tensor per group (1 KiB per wave instruction), 4x fewer memory instructions than the scalar kernel.
+typedef __bf16 bf16x2_k __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_k __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_k(float a, float b) {
+    bf16x2_k v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
 template <int NV>
 __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float* r, const float* stats, const float* g,
-                                                    float* dr, float* dres, float* dgamma, float* dbeta, float* dbias,
-                                                    long rows, int E, DropKey drop) {
+                                                    float* dr, void* dres, int dres_bf16, float* dgamma, float* dbeta,
+                                                    float* dbias, long rows, int E, DropKey drop) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     f32x4 pg[NV], pb[NV], pc[NV], gw[NV];
@@ -431,7 +437,14 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
 #pragma unroll
                     for (int q = 0; q < 4; ++q) vb[q] = v[q] * drop_factor(drop, (uint64_t)row * E + c + q, ks);
                 }
-                if (dres) *reinterpret_cast<f32x4*>(dres + row * E + c) = vb;
+                if (dres) {
+                    if (dres_bf16) {
+                        u32x2_k w = {pack2_k(vb[0], vb[1]), pack2_k(vb[2], vb[3])};
+                        *reinterpret_cast<u32x2_k*>(reinterpret_cast<__bf16*>(dres) + row * E + c) = w;
+                    } else {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dres) + row * E + c) = vb;
+                    }
+                }
                 pc[j] += vb;
             }
         }
@@ -454,20 +467,21 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
     }
 }
 
-int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, float* dres_out,
-                    float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st) {
+int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out,
+                    float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st, int dres_bf16) {
     const unsigned nb = nblocks(rows, 4 * 16, 4096);   // >=16 rows per wave so the atomics are amortised
     const bool al = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) |
                       reinterpret_cast<uintptr_t>(dr) | reinterpret_cast<uintptr_t>(dres_out)) & 15) == 0;
     if (E % 4 == 0 && E <= 1024 && al) {
-#define GG_LN_BWD4(NV) ln_bwd_v4_k<NV><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dgamma, dbeta, dbias, rows, E, drop)
+#define GG_LN_BWD4(NV) ln_bwd_v4_k<NV><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dres_bf16, dgamma, dbeta, dbias, rows, E, drop)
         if (E <= 256) GG_LN_BWD4(1);
         else if (E <= 512) GG_LN_BWD4(2);
         else GG_LN_BWD4(4);
 #undef GG_LN_BWD4
         GG_LAUNCH_CHECK();
     }
-#define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dgamma, dbeta, dbias, rows, E, drop)
+    GG_REQUIRE(!dres_bf16, "bf16 branch-gradient output needs the vectorised LayerNorm backward (E % 4 == 0, aligned)");
+#define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, reinterpret_cast<float*>(dres_out), dgamma, dbeta, dbias, rows, E, drop)
     if (E <= 64) GG_LN_BWD(1);
     else if (E <= 128) GG_LN_BWD(2);
     else if (E <= 256) GG_LN_BWD(4);
@@ -483,6 +497,29 @@ int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const f
 // 4-row-interleaved strip, so a wave reads whole 1 KiB row segments; partial sums are folded through LDS and
 // leave as one atomic per column per workgroup.
 constexpr int CS_ROWS = 256;
+// bf16 input variant (bias gradients of bf16-stored branch gradients): same tiling, 8-byte loads of 4 bf16
+__global__ __launch_bounds__(TPB) void colsum_bf16_k(const __bf16* X, long rows, int N, long ld, float* out) {
+    __shared__ float red[4][256];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 256 + cq * 4;
+    const long r0 = (long)blockIdx.x * 256;
+    const long r1 = min(rows, r0 + 256);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 3 < N) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const u32x2_k w = *reinterpret_cast<const u32x2_k*>(X + r * ld + c0);
+            s[0] += __builtin_bit_cast(float, w[0] << 16);
+            s[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
+            s[2] += __builtin_bit_cast(float, w[1] << 16);
+            s[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = s[j];
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
 __global__ __launch_bounds__(TPB) void colsum_k(const float* X, const float* ref, long rows, int N, long ld, float slope,
                                                 float* out) {
     __shared__ float red[4][256];
@@ -521,9 +558,14 @@ __global__ __launch_bounds__(TPB) void colsum_k(const float* X, const float* ref
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-int k_colsum(const float* X, long rows, int N, long ld, float* out, hipStream_t st) {
+int k_colsum(const void* X, long rows, int N, long ld, float* out, hipStream_t st, int x_bf16) {
     dim3 grid((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((N + 255) / 256));
-    colsum_k<<<grid, TPB, 0, st>>>(X, nullptr, rows, N, ld, 0.f, out);
+    if (x_bf16) {
+        GG_REQUIRE(N % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0, "bf16 colsum needs 4-element alignment");
+        colsum_bf16_k<<<grid, TPB, 0, st>>>(reinterpret_cast<const __bf16*>(X), rows, N, ld, out);
+        GG_LAUNCH_CHECK();
+    }
+    colsum_k<<<grid, TPB, 0, st>>>(reinterpret_cast<const float*>(X), nullptr, rows, N, ld, 0.f, out);
     GG_LAUNCH_CHECK();
 }
 int k_colsum_masked(const float* X, const float* ref, long rows, int N, float slope, float* out, hipStream_t st) {

@@ -37,7 +37,16 @@ __device__ __forceinline__ void headwise_WT_vec(float* out, const float* __restr
     for (int i = tid; i < nh * E; i += TPB) {
         const int h = i / E, e = i % E;
         float acc = 0.f;
-        for (int d = 0; d < dh; ++d) acc += vec[h * dh + d] * W[(long)(row0 + h * dh + d) * E + e];
+        const float* wp = W + (long)(row0 + h * dh) * E + e;
+        int d = 0;
+        for (; d + 8 <= dh; d += 8) {            // 8 independent loads in flight (rows are E floats apart, L2 resident)
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = wp[(long)(d + u) * E];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += vec[h * dh + d + u] * t[u];
+        }
+        for (; d < dh; ++d) acc += vec[h * dh + d] * wp[(long)d * E];
         out[i] = acc;
     }
 }
@@ -59,25 +68,33 @@ __device__ __forceinline__ void headwise_W_vec(float* out, const float* __restri
 __device__ __forceinline__ void rows_dot(float* sc, int SS, const float* __restrict__ x, const float* vecs /*LDS [nh][E]*/, int S,
                                          int E, int nh, float alpha, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
-    for (int s = wave; s < S; s += TPB / 64) {
-        float acc[MAXH];
+    constexpr int RB = 4;                                    // rows per batch per wave
+    for (int s0 = wave * RB; s0 < S; s0 += (TPB / 64) * RB) {
+        float acc[RB][MAXH];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) acc[h] = 0.f;
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h) acc[r][h] = 0.f;
         for (int e = lane * 4; e < E; e += 256) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)s * E + e);
+            f32x4 xv[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) xv[r] = *reinterpret_cast<const f32x4*>(x + (long)min(s0 + r, S - 1) * E + e);
 #pragma unroll
             for (int h = 0; h < MAXH; ++h)
                 if (h < nh) {
                     const f32x4 qv = *reinterpret_cast<const f32x4*>(vecs + h * E + e);
-                    acc[h] += xv[0] * qv[0] + xv[1] * qv[1] + xv[2] * qv[2] + xv[3] * qv[3];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r][h] += xv[r][0] * qv[0] + xv[r][1] * qv[1] + xv[r][2] * qv[2] + xv[r][3] * qv[3];
                 }
         }
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
-            if (h < nh) {
-                const float r = wave_sum(acc[h]);
-                if (lane == 0) sc[h * SS + s] = r * alpha;
-            }
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h)
+                if (h < nh) {
+                    const float v = wave_sum(acc[r][h]);
+                    if (lane == 0 && s0 + r < S) sc[h * SS + s0 + r] = v * alpha;
+                }
     }
 }
 
@@ -132,7 +149,18 @@ __global__ __launch_bounds__(TPB) void sqx_fwd_kernel(const float* __restrict__ 
         float acc[MAXH];                                 // x re-read once from L2, coalesced over e
 #pragma unroll
         for (int h = 0; h < MAXH; ++h) acc[h] = 0.f;
-        for (int s = 0; s < S; ++s) {
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = xn[(long)(s + u) * E + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int h = 0; h < MAXH; ++h)
+                    if (h < nh) acc[h] += sc[h * SS + s + u] * xv[u];
+        }
+        for (; s < S; ++s) {
             const float xv = xn[(long)s * E + e];
 #pragma unroll
             for (int h = 0; h < MAXH; ++h)
@@ -197,17 +225,25 @@ __global__ __launch_bounds__(TPB) void sqx_bwd_kernel(const float* __restrict__ 
             a_qt[h] = h < nh ? qt[h * E + e] : 0.f;
             a_dqt[h] = 0.f;
         }
-        for (int s = 0; s < S; ++s) {
-            const float xv = xn[(long)s * E + e];
-            float o = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float xv[8];
 #pragma unroll
-            for (int h = 0; h < MAXH; ++h)
-                if (h < nh) {
-                    const float g = ds[h * SS + s];
-                    o += pr[h * SS + s] * a_dxb[h] + g * a_qt[h];
-                    a_dqt[h] += g * xv;
+            for (int u = 0; u < 8; ++u) xv[u] = xn[(long)min(s0 + u, S - 1) * E + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u;
+                if (s < S) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int h = 0; h < MAXH; ++h)
+                        if (h < nh) {
+                            const float g = ds[h * SS + s];
+                            o += pr[h * SS + s] * a_dxb[h] + g * a_qt[h];
+                            a_dqt[h] += g * xv[u];
+                        }
+                    dxn[(long)s * E + e] = o;
                 }
-            dxn[(long)s * E + e] = o;
+            }
         }
 #pragma unroll
         for (int h = 0; h < MAXH; ++h)

@@ -48,7 +48,8 @@ constexpr float LN_EPS = 1e-5f;
 
 // KSL: length of the K slice kept register-resident (64 | 128 | 256); K must be a multiple of KSL so that
 // every MFMA chain below is straight-line code with compile-time fragment indices.
-template <int TOK, int NT_RES, int KSL>
+// XB / YB: activations read / written as bf16 (tensors that only ever feed bf16 MFMA operands are stored in bf16)
+template <int TOK, int NT_RES, int KSL, bool XB, bool YB>
 __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const TlinP p) {
     constexpr int TT = TOK / 32;                       // 32-token fragment sets per wave
     constexpr int NACC = NT_RES > 0 ? NT_RES : 1;
@@ -97,14 +98,19 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
     bf16x8 xf[TT][KSL / 16];
 
     // staged rows of this lane (rows past the end re-read the last valid token: never stored) and their
-    // FiLM group, in 32-bit arithmetic, computed once
-    int rtok[TOK / 4], rgrp[TOK / 4];
+    // FiLM group, in 32-bit arithmetic, computed once.  One load instruction covers 64 reduction elements of
+    // RPI rows: fp32 -> 16 lanes x 16 B per row (4 rows), bf16 -> 8 lanes x 16 B per row (8 rows).
+    constexpr int RPI = XB ? 8 : 4;
+    constexpr int NLD = TOK / RPI;
+    const int lrow = XB ? (lane >> 3) : (lane >> 4);
+    const int lcol = XB ? 8 * (lane & 7) : 4 * (lane & 15);      // element offset inside the 64-wide window
+    int rtok[NLD], rgrp[NLD];
     {
-        const int t0 = (int)tok0 + (lane >> 4), lt = (int)last_tok;
+        const int t0 = (int)tok0 + lrow, lt = (int)last_tok;
 #pragma unroll
-        for (int i = 0; i < TOK / 4; ++i) {
-            rtok[i] = min(t0 + 4 * i, lt);
-            rgrp[i] = p.film_g ? rtok[i] / p.film_group : 0;
+        for (int i = 0; i < NLD; ++i) {
+            rtok[i] = min(t0 + RPI * i, lt);
+            rgrp[i] = (!XB && p.film_g) ? rtok[i] / p.film_group : 0;
         }
     }
     load_chunk(0, 0);
@@ -114,25 +120,33 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
         // ---- stage this wave's X slice: HBM -> (fp32 -> bf16, FiLM) -> LDS slab -> B fragments --------
 #pragma unroll
         for (int q4 = 0; q4 < KSL / 64; ++q4) {
-            const int kbase = ks * KSL + q4 * 64 + 4 * (lane & 15);
-            f32x4 v[TOK / 4];
+            const int kbase = ks * KSL + q4 * 64 + lcol;
+            if constexpr (XB) {
+                const __bf16* Xb = reinterpret_cast<const __bf16*>(p.X);
+                u32x4 v[NLD];
 #pragma unroll
-            for (int i = 0; i < TOK / 4; ++i)
-                v[i] = *reinterpret_cast<const f32x4*>(p.X + (long)rtok[i] * p.ldx + kbase);
-            if (p.film_g) {
+                for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const u32x4*>(Xb + (long)rtok[i] * p.ldx + kbase);
 #pragma unroll
-                for (int i = 0; i < TOK / 4; ++i) {
-                    const long fo = (long)rgrp[i] * p.film_ld + kbase;
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.film_g + fo);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.film_b + fo);
-                    v[i] = g * v[i] + b;
+                for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(&Xs[wave][(i * RPI + lrow) * XLD + lcol]) = v[i];
+            } else {
+                const float* Xf = reinterpret_cast<const float*>(p.X);
+                f32x4 v[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xf + (long)rtok[i] * p.ldx + kbase);
+                if (p.film_g) {
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        const long fo = (long)rgrp[i] * p.film_ld + kbase;
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.film_g + fo);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.film_b + fo);
+                        v[i] = g * v[i] + b;
+                    }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < TOK / 4; ++i) {
-                const int row = i * 4 + (lane >> 4);
-                u32x2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
-                *reinterpret_cast<u32x2*>(&Xs[wave][row * XLD + 4 * (lane & 15)]) = w;
+                for (int i = 0; i < NLD; ++i) {
+                    u32x2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
+                    *reinterpret_cast<u32x2*>(&Xs[wave][(i * RPI + lrow) * XLD + lcol]) = w;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -201,13 +215,25 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
                     const bool valid = tok < p.M;
                     const long tokc = valid ? tok : last_tok;
                     const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
-                    float* yb = p.Y + yrow * p.ldy + nt * 32 + 4 * h;
-                    const float* mb = p.mask_ref ? p.mask_ref + tokc * p.ldref + nt * 32 + 4 * h : nullptr;
+                    const long yoff = yrow * p.ldy + nt * 32 + 4 * h;
+                    const long moff = tokc * p.ldref + nt * 32 + 4 * h;
                     f32x4 mm[4], yy[4], bb[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        mm[g] = mb ? *reinterpret_cast<const f32x4*>(mb + 8 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
-                        yy[g] = p.accumulate ? *reinterpret_cast<const f32x4*>(yb + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        mm[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (p.mask_ref) {
+                            if (p.mask_bf16) {     // only the sign matters: expand the four bf16 to fp32 bit patterns
+                                const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.mask_ref) + moff + 8 * g);
+                                mm[g] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                                              __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                            } else {
+                                mm[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask_ref) + moff + 8 * g);
+                            }
+                        }
+                        yy[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (!YB) {
+                            if (p.accumulate) yy[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(p.Y) + yoff + 8 * g);
+                        }
                         bb[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
@@ -223,12 +249,19 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tokc * p.drop_ld + n + j, ksd);
                         }
-                        if (mb) {
+                        if (p.mask_ref) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = mm[g][j] > 0.f ? v[j] * p.mask_scale : 0.f;
                         }
                         v += yy[g];
-                        if (valid) *reinterpret_cast<f32x4*>(yb + 8 * g) = v;
+                        if (valid) {
+                            if constexpr (YB) {
+                                u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                                *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.Y) + yoff + 8 * g) = w;
+                            } else {
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff + 8 * g) = v;
+                            }
+                        }
                     }
                 }
                 if (more) store_chunk(buf ^ 1);
@@ -246,7 +279,7 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
         const long tokc = valid ? tok : last_tok;        // clamped row: loads are unconditional (batched, no exec branches)
         const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
         const float* resp = p.res ? p.res + (tokc % p.res_rows) * p.ldres : nullptr;
-        float* yb = p.Y + yrow * p.ldy;
+        float* yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy;
         float sum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT_RES; ++nt) {
@@ -325,12 +358,20 @@ __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ 
     }
 }
 
-template <int TOK, int NT_RES, int KSL>
+template <int TOK, int NT_RES, int KSL, bool XB, bool YB>
 int launch(const TlinP& p, hipStream_t st) {
     const long blocks = (p.M + 4 * TOK - 1) / (4 * TOK);
-    hipLaunchKernelGGL((tlin_kernel<TOK, NT_RES, KSL>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((tlin_kernel<TOK, NT_RES, KSL, XB, YB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
+}
+template <int TOK, int NT_RES, int KSL>
+int launch_t(const TlinP& p, hipStream_t st) {
+    if (NT_RES == 0) {
+        if (p.x_bf16) return p.y_bf16 ? launch<TOK, NT_RES, KSL, true, true>(p, st) : launch<TOK, NT_RES, KSL, true, false>(p, st);
+        return p.y_bf16 ? launch<TOK, NT_RES, KSL, false, true>(p, st) : launch<TOK, NT_RES, KSL, false, false>(p, st);
+    }
+    return p.x_bf16 ? launch<TOK, NT_RES, KSL, true, false>(p, st) : launch<TOK, NT_RES, KSL, false, false>(p, st);
 }
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 inline bool needs_resident(const TlinP& p) { return p.ln_g || p.res || !(p.K == 64 || p.K == 128 || p.K == 256); }
@@ -341,14 +382,15 @@ inline bool needs_resident(const TlinP& p) { return p.ln_g || p.res || !(p.K == 
 bool tlin_supported(const TlinP& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
     if (p.N % 32 || p.K % 64) return false;
-    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % 4 || p.ldy % 4 || p.ldw % 8) return false;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % (p.x_bf16 ? 8 : 4) || p.ldy % 4 || p.ldw % 8) return false;
     if (p.bias && !al16(p.bias)) return false;
-    if (p.film_g && (!al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group <= 0)) return false;
+    if (p.film_g && (p.x_bf16 || !al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group <= 0)) return false;
     if (p.mask_ref && (!al16(p.mask_ref) || p.ldref % 4)) return false;
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
+    if (p.y_bf16 && p.accumulate) return false;
     if (!needs_resident(p)) return true;
-    if (p.mask_ref || p.act_relu) return false;            // not implemented in the resident epilogue
+    if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue
     if (p.N == 256) return p.K % 256 == 0;
     if (p.N == 128) return p.K % 128 == 0;
     if (p.N == 64) return p.K % 64 == 0;
@@ -358,13 +400,13 @@ bool tlin_supported(const TlinP& p) {
 int tlin(const TlinP& p, hipStream_t st) {
     GG_REQUIRE(tlin_supported(p), "tlin: unsupported shape / alignment");
     if (!needs_resident(p)) {
-        if (p.K == 256) return launch<32, 0, 256>(p, st);
-        if (p.K == 128) return launch<32, 0, 128>(p, st);
-        return launch<32, 0, 64>(p, st);
+        if (p.K == 256) return launch_t<32, 0, 256>(p, st);
+        if (p.K == 128) return launch_t<32, 0, 128>(p, st);
+        return launch_t<32, 0, 64>(p, st);
     }
-    if (p.N == 256) return launch<32, 8, 256>(p, st);
-    if (p.N == 128) return launch<32, 4, 128>(p, st);
-    return launch<32, 2, 64>(p, st);
+    if (p.N == 256) return launch_t<32, 8, 256>(p, st);
+    if (p.N == 128) return launch_t<32, 4, 128>(p, st);
+    return launch_t<32, 2, 64>(p, st);
 }
 
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {

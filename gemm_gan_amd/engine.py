@@ -155,6 +155,9 @@ class Engine:
     def set_flash(self, on: bool):
         L.check(self.lib.gg_set_flash(self.h, int(on)))
 
+    def set_bstore(self, on: bool):
+        L.check(self.lib.gg_set_bstore(self.h, int(on)))
+
     def set_sqx(self, on: bool):
         L.check(self.lib.gg_set_sqx(self.h, int(on)))
 
@@ -168,13 +171,14 @@ class Engine:
         """Copy of a named internal activation buffer of the last call (tests only)."""
         ptr, n = C.c_void_p(), C.c_int64()
         L.check(self.lib.gg_debug_buffer(self.h, name.encode(), C.byref(ptr), C.byref(n)))
-        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        is_bf16 = self.lib.gg_debug_buffer_is_bf16(self.h, name.encode()) == 1
+        out = torch.empty(n.value, dtype=torch.bfloat16 if is_bf16 else torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         rt = C.CDLL("libamdhip64.so")
-        rc = rt.hipMemcpy(C.c_void_p(out.data_ptr()), ptr, C.c_size_t(4 * n.value), C.c_int(3))   # hipMemcpyDeviceToDevice
+        rc = rt.hipMemcpy(C.c_void_p(out.data_ptr()), ptr, C.c_size_t(out.element_size() * n.value), C.c_int(3))   # DeviceToDevice
         if rc != 0:
             raise RuntimeError(f"hipMemcpy failed: {rc}")
-        return out
+        return out.float()
 
     def profile(self, on: bool):
         L.check(self.lib.gg_profile_enable(self.h, int(on)))

@@ -134,6 +134,7 @@ int gg_set_dropout(gg_engine* e, float p);            /* parity runs use 0 */
 int gg_set_seed(gg_engine* e, uint64_t seed);
 int gg_set_precision(gg_engine* e, int precision);    /* GG_PREC_* ; may be switched between calls */
 int gg_set_flash(gg_engine* e, int on);               /* fused attention kernels in bf16 mode (default on) */
+int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
 int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
@@ -150,6 +151,7 @@ int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, in
 /* device pointer + element count of a named internal activation buffer of the LAST call, e.g.
  * "D.x0", "D.L0.P", "G.c", "X2", "gp_grad" (list in engine.hip); lets tests localise a mismatch. */
 int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel);
+int gg_debug_buffer_is_bf16(gg_engine* e, const char* name);   /* 1 if that buffer currently holds bf16 elements */
 /* ---- live per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ---------
  * gg_profile_enable(e, 1) brackets every subsequent GEMM launch with an event pair taken from a pool;
  * gg_profile_collect synchronises the events and aggregates per kernel class (= kernel symbol:

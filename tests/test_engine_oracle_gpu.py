@@ -262,12 +262,14 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     ck = Checker(f"tlin vs tile GEMM (bf16) {case} dropout={dropout}", 2e-3)
     a, b = out[True], out[False]
     for n in names:
-        ck.check(n, a[n], b[n])
+        # qkv / h are stored in bf16 on the tlin path (2^-9 element rounding), fp32 on the tile-GEMM path
+        ck.check(n, a[n], b[n], tol=6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx") else None)
     for n in gnames:
         # the critic's conditioning vector differs by ~5e-4 between the two bf16 paths (values that sit on a bf16
         # rounding boundary re-round differently); on these 6-12 sample batches that flips a few ReLU gates of
         # the critic head, which moves d(loss)/d(x_fake) and everything downstream by percents
-        ck.check("generator pass " + n, a["gen:" + n], b["gen:" + n], tol=0.25 if n in ("dxfake", "dc") else None)
+        ck.check("generator pass " + n, a["gen:" + n], b["gen:" + n],
+                 tol=0.25 if n in ("dxfake", "dc") else (6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx") else None))
     for k in a["gstate"]:
         from gpu_util import diag as _d
         _d(f"      dG {k:60s} cos {_cos(a['gstate'][k], b['gstate'][k]):.6f}")
@@ -277,4 +279,40 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     cd, cg = _cos(a["g"], b["g"]), _cos(a["gg"], b["gg"])
     diag(f"   flat gradient cosine tlin vs generic: critic {cd:.6f} generator {cg:.6f}")
     assert cd > 0.999 and cg > 0.99, (cd, cg)
+    ck.done()
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
+def test_bf16_operand_storage_is_numerically_transparent(case):
+    """Storing the MFMA-operand-only tensors (qkv, attention context, FFN hidden and the matching branch
+    gradients) in bf16 instead of rounding them at load time must not change the results beyond the bf16
+    rounding of the few fp32 uses of those tensors (softmax delta = sum dO*O, bias column sums)."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    out = {}
+    names = ["D.L0.qkv", "D.L0.ctx", "D.L0.x1", "D.L0.h", "D.L1.x2", "D.c"]
+    for on in (False, True):
+        eng.set_bstore(on)
+        eng.set_seed(5)
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(), **{n: eng.debug_buffer(n) for n in names})
+    ck = Checker(f"bf16 operand storage on vs off {case}", 6e-3)
+    a, b = out[True], out[False]
+    for n in names:
+        ck.check(n, a[n], b[n])
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=1e-2)
+    cs = _cos(a["g"], b["g"])
+    from gpu_util import diag
+    diag(f"   flat critic gradient cosine bf16-storage on vs off: {cs:.6f}")
+    assert cs > 0.999, cs
     ck.done()
