@@ -63,6 +63,7 @@ SYMBOLS = {
     "gg_set_tlin": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_sqx": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_bstore": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_wgrad": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_debug_buffer_is_bf16": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gg_reset_optimizer_steps": (C.c_int, [C.c_void_p]),
     "gg_get_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),

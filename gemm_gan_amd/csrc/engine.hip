@@ -129,6 +129,7 @@ struct gg_engine {
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
     float *s_delta;
     int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
+    int wgrad_on = 1;          // dedicated long-reduction weight-gradient kernel (bf16 mode)
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt;
@@ -367,6 +368,32 @@ int lin_bwd_data(Ctx& c, const float* dY, long ldy, const float* W, long ldw, fl
 // dW[N,K] += dY[M,N]^T @ X[M,K]     (reduction over the M rows, split over workgroups, fp32 atomics)
 int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K,
                    int dy_bf16 = 0, int x_bf16 = 0) {
+    gg_engine* e = c.e;
+    if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
+        e->launches++;
+        gg_engine::ProfRec r;
+        if (e->prof_on) {
+            if (e->prof_next + 2 > e->prof_pool.size()) {
+                for (int i = 0; i < 4096; ++i) {
+                    hipEvent_t ev;
+                    GG_CHECK_HIP(hipEventCreate(&ev));
+                    e->prof_pool.push_back(ev);
+                }
+            }
+            r.cls = 10;
+            r.flops = 2.0 * M * N * (double)K;
+            r.bytes = (double)M * N * (dy_bf16 ? 2 : 4) + (double)M * K * (x_bf16 ? 2 : 4) + 4.0 * N * K;
+            r.e0 = e->prof_pool[e->prof_next++];
+            r.e1 = e->prof_pool[e->prof_next++];
+            GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
+        }
+        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st));
+        if (e->prof_on) {
+            GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
+            e->prof_recs.push_back(r);
+        }
+        return 0;
+    }
     GemmP p;
     p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
     p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = dy_bf16; p.b_bf16 = x_bf16;
@@ -1092,6 +1119,11 @@ int gg_set_tlin(gg_engine* e, int on) {
     e->tlin_on = on != 0;
     return 0;
 }
+int gg_set_wgrad(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->wgrad_on = on != 0;
+    return 0;
+}
 int gg_set_bstore(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->bstore_on = on != 0;
@@ -1141,7 +1173,8 @@ int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
     static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                                    "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
-    e->prof_agg.assign(10, gg_engine::ProfAgg());
+    e->prof_agg.assign(11, gg_engine::ProfAgg());
+    e->prof_agg[10].name = "wgrad_kernel";
     for (int i = 0; i < 8; ++i) e->prof_agg[i].name = names[i];
     e->prof_agg[8].name = "tlin_kernel<64,stream>";
     e->prof_agg[9].name = "tlin_kernel<32,resident>";

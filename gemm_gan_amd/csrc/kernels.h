@@ -139,6 +139,11 @@ int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* 
 int sqx_attn_bwd(const float* dctx, const float* q, const float* x, const float* Win, const float* probs, float* dx, float* dq,
                  float* dqt, int N, int S, int E, int nh, hipStream_t st);
 
+// weight gradient dW[N,K] += dY[M,N]^T X[M,K] over long token reductions (wgrad.hip), operands fp32 or bf16 --------
+bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, long M, int N, int K);
+int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
+          hipStream_t st);
+
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
 enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };

@@ -1,0 +1,210 @@
+// Weight-gradient kernel:  dW[N,K] += dY[M,N]^T . X[M,K]   (reduction over the M ~ 1e5 token rows, bf16 MFMA)
+//
+// Both operands are stored token-major (the reduction index is the SLOW index of both), which is the worst
+// case for an MFMA fragment (8 consecutive reduction elements per lane).  Instead of transposing while
+// staging, token chunks are copied row-major into LDS with full-line loads and BOTH operands are fetched
+// with ds_read_b64_tr_b16 (hardware transpose read: a 16-lane group reads a 4-token x 16-feature block and
+// each lane receives one feature column of 4 tokens).
+//
+// Decomposition: a workgroup (4 waves) owns a 128 (n) x 256 (k) panel of dW - wave w the 32-row slice
+// n in [32w, 32w+32) as 8 MFMA 32x32 accumulators (128 accumulator registers) - and a contiguous range
+// of tokens; panels x token-splits fill the chip.  Per 32-token chunk a wave issues 2 x 2 A-fragment and
+// 8 x 2 B-fragment transpose reads for 32 MFMAs.  Partial panels are added to dW with fp32 atomics whose wave
+// instructions cover two 128-byte row segments (the fast atomic shape).
+#include "kernels.h"
+
+namespace gg {
+
+namespace {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+constexpr int WT = 1;                            // 32-row accumulator tiles per wave along n
+constexpr int PN = 128 * WT, PK = 256, CT = 32;  // panel rows / cols, tokens per chunk
+constexpr int LDY = PN + 32, LDX = PK + 32;      // bf16 per LDS row: 144 dwords (16 mod 64) -> conflict-free transpose reads
+
+// A / B fragment of the 16-token step s2 for the 32 features starting at col0: element j of lane (c, h) is
+// token 16*s2 + 8*h + j, feature col0 + c   (natural k order: both operands come from LDS)
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int ld, int col0, int s2, int lane) {
+    const int i = lane & 15, grp = lane >> 4;
+    const int hh = grp >> 1, colhalf = grp & 1;
+    const __bf16* p0 = img + (16 * s2 + 8 * hh + (i >> 2)) * ld + col0 + 16 * colhalf + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ld));
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// global -> registers -> LDS staging of one [CT tokens x W features] chunk (W = 256), 4 x 16-byte pieces / thread
+template <bool BF, int W>
+struct Stager {
+    static constexpr int PPR = W / (BF ? 8 : 4);             // 16-byte pieces per row
+    static constexpr int NP = CT * PPR / 256;                // pieces per thread
+    u32x4 r[NP];
+    // Unconditional loads (rows / columns past the end are clamped to valid addresses so nothing branches and all
+    // pieces are in flight together); `zero` blanks the out-of-range pieces afterwards - needed for dY only: a zero
+    // dY row/column contributes nothing whatever X holds, and out-of-range X columns only feed unstored outputs.
+    __device__ __forceinline__ void load(const void* base, long ld, long tok0, long tok_end, int col0, int cols_valid, int tid, bool zero) {
+        if constexpr (BF) {
+            const __bf16* p = reinterpret_cast<const __bf16*>(base);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {                        // piece = 8 bf16
+                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const long t = min(tok0 + row, tok_end - 1);
+                const int cc = min(8 * pc, cols_valid - 8);
+                r[i] = *reinterpret_cast<const u32x4*>(p + t * ld + col0 + cc);
+                if (zero && (tok0 + row >= tok_end || 8 * pc >= cols_valid)) r[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        } else {
+            const float* p = reinterpret_cast<const float*>(base);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {                        // piece = 4 fp32
+                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const long t = min(tok0 + row, tok_end - 1);
+                const int cc = min(4 * pc, cols_valid - 4);
+                r[i] = *reinterpret_cast<const u32x4*>(p + t * ld + col0 + cc);
+                if (zero && (tok0 + row >= tok_end || 4 * pc >= cols_valid)) r[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* img, int ld, int tid) const {
+        if constexpr (BF) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                *reinterpret_cast<u32x4*>(img + row * ld + 8 * pc) = r[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
+                u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+            }
+        }
+    }
+};
+
+template <bool YB, bool XB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
+                                                    float* __restrict__ dW, long ldw, long M, int N, int K, int splits) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
+    auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
+    auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int panels_k = (K + PK - 1) / PK;
+    const int panel = blockIdx.x / splits, split = blockIdx.x % splits;
+    const int n0 = (panel / panels_k) * PN, k0 = (panel % panels_k) * PK;
+    const int nvalid = min(PN, N - n0), kvalid = min(PK, K - k0);
+    // token range of this split, in whole chunks
+    const long chunks = (M + CT - 1) / CT;
+    const long c_beg = chunks * split / splits, c_end = chunks * (split + 1) / splits;
+    if (c_beg >= c_end) return;
+
+    f32x16 acc[WT][8];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    Stager<YB, PN> sy;
+    Stager<XB, PK> sx;
+    sy.load(dY, ldy, c_beg * CT, M, n0, nvalid, tid, true);
+    sx.load(X, ldx, c_beg * CT, M, k0, kvalid, tid, false);
+    sy.store(Ysb(0), LDY, tid);
+    sx.store(Xsb(0), LDX, tid);
+    __syncthreads();
+    for (long ch = c_beg; ch < c_end; ++ch) {
+        const int buf = (int)((ch - c_beg) & 1);
+        const bool more = ch + 1 < c_end;
+        if (more) {
+            sy.load(dY, ldy, (ch + 1) * CT, M, n0, nvalid, tid, true);
+            sx.load(X, ldx, (ch + 1) * CT, M, k0, kvalid, tid, false);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 af[WT];
+#pragma unroll
+            for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bf16x8 bf = frag_tr(Xsb(buf), LDX, b * 32, s2, lane);
+#pragma unroll
+                for (int a = 0; a < WT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+            }
+        }
+        if (more) {
+            sy.store(Ysb(buf ^ 1), LDY, tid);
+            sx.store(Xsb(buf ^ 1), LDX, tid);
+        }
+        __syncthreads();
+    }
+    // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
+    float* wbase = dW + (long)(n0 + wave * (32 * WT) + 4 * h) * ldw + k0 + c;
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b * 32 + c < kvalid) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = a * 32 + (i & 3) + 8 * (i >> 2);       // row inside the wave's 64-row slice (minus 4h)
+                    if (wave * (32 * WT) + 4 * h + rr < nvalid) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one tile's accumulators at a time: no mass copy-out (spills)
+        }
+}
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+}  // namespace
+
+bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, long M, int N, int K) {
+    if (M < 4096 || N % 8 || K % 8 || N < 8 || K < 8) return false;              // short reductions stay on the generic split-K GEMM
+    if (!al16(dY) || !al16(X)) return false;
+    if (ldy % (dy_bf16 ? 8 : 4) || ldx % (x_bf16 ? 8 : 4)) return false;
+    return true;
+}
+
+int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
+          hipStream_t st) {
+    GG_REQUIRE(wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K), "wgrad: unsupported shape / alignment");
+    const int panels = ((N + PN - 1) / PN) * ((K + PK - 1) / PK);
+    const long chunks = (M + CT - 1) / CT;
+    // one workgroup per CU (256 accumulator registers => one wave per SIMD): panels x splits ~ 256; every extra
+    // split costs a 256 KB atomic panel add, every missing one idles a CU
+    int splits = (int)std::max<long>(1, std::min<long>(chunks / 8, (256 + panels - 1) / panels));
+    const dim3 grid((unsigned)(panels * splits));
+    constexpr int SMEM = 2 * CT * (LDY + LDX) * 2;
+#define GG_WG(YB, XB)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB>),                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits); \
+    } while (0)
+    if (dy_bf16 && x_bf16) GG_WG(true, true);
+    else if (dy_bf16) GG_WG(true, false);
+    else if (x_bf16) GG_WG(false, true);
+    else GG_WG(false, false);
+#undef GG_WG
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gg

@@ -155,6 +155,9 @@ class Engine:
     def set_flash(self, on: bool):
         L.check(self.lib.gg_set_flash(self.h, int(on)))
 
+    def set_wgrad(self, on: bool):
+        L.check(self.lib.gg_set_wgrad(self.h, int(on)))
+
     def set_bstore(self, on: bool):
         L.check(self.lib.gg_set_bstore(self.h, int(on)))
 

@@ -134,6 +134,7 @@ int gg_set_dropout(gg_engine* e, float p);            /* parity runs use 0 */
 int gg_set_seed(gg_engine* e, uint64_t seed);
 int gg_set_precision(gg_engine* e, int precision);    /* GG_PREC_* ; may be switched between calls */
 int gg_set_flash(gg_engine* e, int on);               /* fused attention kernels in bf16 mode (default on) */
+int gg_set_wgrad(gg_engine* e, int on);               /* long-reduction weight-gradient kernel in bf16 mode (default on) */
 int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */

@@ -316,3 +316,32 @@ def test_bf16_operand_storage_is_numerically_transparent(case):
     diag(f"   flat critic gradient cosine bf16-storage on vs off: {cs:.6f}")
     assert cs > 0.999, cs
     ck.done()
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
+def test_weight_gradient_kernel_matches_split_k_gemm(case):
+    """wgrad.hip (row-major LDS chunks, both MFMA operands via hardware transpose reads, panel accumulators)
+    against the generic split-K tile GEMM: same bf16 operand values, only the fp32 summation order differs."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], max(c["B"], 70), c["P"], c["T"]          # >= 4096 token rows so the kernel engages
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    out = {}
+    for on in (False, True):
+        eng.set_wgrad(on)
+        eng.set_seed(5)
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        out[on] = {k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()}
+    ck = Checker(f"wgrad kernel vs split-K GEMM {case}", 2e-3)
+    for k in out[True]:
+        if k.endswith("weight") and "transformer" in k:
+            ck.check(k, out[True][k], out[False][k])
+    ck.done()
