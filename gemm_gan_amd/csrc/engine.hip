@@ -129,6 +129,7 @@ struct gg_engine {
     float *sPd, *sdP, *sdqkv, *sdx, *sdr, *sdres, *sdh, *sdctx;
     float *s_delta;
     int flash = 1;             // use the fused attention kernels when precision == bf16 and the shape allows
+    int small_on = 1;          // latency-optimised kernel for few-tile GEMMs (bf16 mode)
     int wgrad_on = 1;          // dedicated long-reduction weight-gradient kernel (bf16 mode)
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
@@ -307,7 +308,8 @@ int run_gemm(Ctx& c, const GemmP& p) {
     gg_engine* e = c.e;
     e->launches++;
     const bool bf16 = e->precision == GG_PREC_BF16;
-    if (!e->prof_on) return bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st);
+    const bool small = bf16 && e->small_on && gemm_small_wanted(p);
+    if (!e->prof_on) return small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
     if (e->prof_next + 2 > e->prof_pool.size()) {
         for (int i = 0; i < 4096; ++i) {
             hipEvent_t ev;
@@ -323,7 +325,8 @@ int run_gemm(Ctx& c, const GemmP& p) {
     r.e0 = e->prof_pool[e->prof_next++];
     r.e1 = e->prof_pool[e->prof_next++];
     GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
-    int rc = bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st);
+    if (small) r.cls = 11;
+    int rc = small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
     GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
     e->prof_recs.push_back(r);
     return rc;
@@ -1173,7 +1176,8 @@ int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
     static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                                    "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
-    e->prof_agg.assign(11, gg_engine::ProfAgg());
+    e->prof_agg.assign(12, gg_engine::ProfAgg());
+    e->prof_agg[11].name = "gemm_small_kernel";
     e->prof_agg[10].name = "wgrad_kernel";
     for (int i = 0; i < 8; ++i) e->prof_agg[i].name = names[i];
     e->prof_agg[8].name = "tlin_kernel<64,stream>";
@@ -1262,6 +1266,16 @@ int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
     return gemm_f32(p, (hipStream_t)stream);
 }
 
+
+int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                       int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                       void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_small(p, (hipStream_t)stream);
+}
 
 int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                       int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,

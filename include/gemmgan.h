@@ -146,6 +146,9 @@ int gg_set_optimizer_step(gg_engine* e, int role, int step);
 int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                  int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                  float slope, int accumulate, void* stream);
+int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                       int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
+                       float slope, int accumulate, void* stream);
 int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                       int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                       float slope, int accumulate, void* stream);

@@ -108,3 +108,24 @@ def test_gemm_bf16_random(layA, layB):
     ck.check("alpha+bias+accumulate+leaky", run_gemm(A, B, M, N, K, layA, layB, alpha=0.5, bias=bias, act=1, slope=0.1,
                                                      C0=C0, accumulate=1, kernel="gg_test_gemm_bf16"), want)
     ck.done()
+
+
+@pytest.mark.parametrize("layA", [0, 1])
+@pytest.mark.parametrize("layB", [0, 1])
+def test_gemm_small_layouts_exact_integer(layA, layB):
+    """64x64-tile / one-shot-K kernel used for the few-tile products: exact-integer check of every layout,
+    ragged sizes, K spanning several 256-deep slabs, split-K, epilogue."""
+    ck = Checker(f"gemm_small exact integer layA={layA} layB={layB}", 0.0)
+    for (M, N, K, sk) in [(32, 32, 16, 1), (64, 64, 256, 1), (200, 136, 72, 1), (257, 64, 600, 1), (5, 37, 69, 1), (256, 256, 1000, 4)]:
+        Am, Bm, A, B = operands(M, N, K, layA, layB, True)
+        out = run_gemm(A, B, M, N, K, layA, layB, splitk=sk, kernel="gg_test_gemm_small")
+        ck.check(f"{M}x{N}x{K} sk{sk}", out, (Am.double() @ Bm.double()).float())
+    M, N, K = 130, 70, 300
+    Am, Bm, A, B = operands(M, N, K, layA, layB, True)
+    bias = torch.arange(N, device="cuda").float()
+    C0 = torch.ones(M, N, device="cuda")
+    want = 2.0 * (Am.double() @ Bm.double()) + bias.double().cpu() + 1.0
+    want = torch.where(want > 0, want, 0.5 * want)
+    ck.check("alpha+bias+accumulate+leaky", run_gemm(A, B, M, N, K, layA, layB, alpha=2.0, bias=bias, act=1, slope=0.5, C0=C0,
+                                                     accumulate=1, kernel="gg_test_gemm_small"), want.float())
+    ck.done()
