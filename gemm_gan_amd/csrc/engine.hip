@@ -439,7 +439,12 @@ int try_tlin(Ctx& c, const TlinP& p) {
         gg_engine::ProfRec r;
         r.cls = 8 + ((p.ln_g || p.res || p.K > 256) ? 1 : 0);
         r.flops = 2.0 * p.M * p.N * (double)p.K;
-        r.bytes = 4.0 * ((double)p.M * p.K + (double)p.M * p.N * (p.ln_g ? 2 : 1) + (p.res ? (double)p.M * p.N : 0) + (p.mask_ref ? (double)p.M * p.N : 0)) + 2.0 * p.N * p.K;
+        // algorithmic bytes at the element sizes actually stored: X once, Y once (+ LayerNorm output), residual,
+        // previous Y when accumulating, sign-mask reference, bf16 weights once
+        const double MN = (double)p.M * p.N;
+        r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MN + (p.ln_g ? 4.0 * MN : 0.0) +
+                  (p.res ? 4.0 * MN : 0.0) + (p.accumulate ? 4.0 * MN : 0.0) + (p.mask_ref ? (p.mask_bf16 ? 2.0 : 4.0) * MN : 0.0) +
+                  2.0 * p.N * p.K;
         r.e0 = e->prof_pool[e->prof_next++];
         r.e1 = e->prof_pool[e->prof_next++];
         if (hipEventRecord(r.e0, c.st) != hipSuccess) return -1;

@@ -18,6 +18,7 @@
 //   resident (NT_RES = N/32 <= 8): all N accumulators resident, K streamed in slices of 256, TOK = 32;
 //                                  enables the fused residual + LayerNorm epilogue (N = E).
 #include "kernels.h"
+#include <type_traits>
 
 namespace gg {
 
@@ -43,32 +44,105 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-constexpr int XLD = 64 + 8;         // bf16 per LDS row of the X staging slab (144 B)
 constexpr float LN_EPS = 1e-5f;
 
-// KSL: length of the K slice kept register-resident (64 | 128 | 256); K must be a multiple of KSL so that
-// every MFMA chain below is straight-line code with compile-time fragment indices.
-// XB / YB: activations read / written as bf16 (tensors that only ever feed bf16 MFMA operands are stored in bf16)
-template <int TOK, int NT_RES, int KSL, bool XB, bool YB>
-__global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const TlinP p) {
-    constexpr int TT = TOK / 32;                       // 32-token fragment sets per wave
-    constexpr int NACC = NT_RES > 0 ? NT_RES : 1;
-    constexpr int WLD = KSL + 8;                       // bf16 per LDS row of a weight chunk
-    constexpr int PIECES = KSL / 8;                    // 16-byte pieces per weight row
-    constexpr int WLOADS = (32 * PIECES + 255) / 256;  // pieces per thread per chunk
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][32 * (KSL + 8)];
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[4][TOK * XLD];
+
+// ---------------------------------------------------------------------------------------------------------------
+// Both kernels are latency-structured for one / two waves per SIMD: every HBM load a wave tile needs is issued in
+// one batch (activation slice, then the residual / accumulate rows for the epilogue), small per-feature vectors
+// (bias, LayerNorm gamma / beta) sit in LDS, and no load follows a store inside a tile.  Measured ceiling for this
+// traffic shape with batched loads at one workgroup per CU: 4.5 - 5.1 TB/s (tools/bw_probe.hip, mix_probe).
+// ---------------------------------------------------------------------------------------------------------------
+
+// stages rows [tok0, tok0+32) x [k0, k0+W) of X (fp32 or bf16, FiLM optional) as bf16 into the wave-private slab xs
+// (row stride LD elements).  GB bounds the loads in flight (registers): all of them for bf16, halves for fp32.
+template <int W, int LD, bool XB>
+__device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, int last_tok, int k0, int lane) {
+    // the row offsets are recomputed per call (32-bit, a few VALU ops) instead of living in registers across the
+    // K loop: the empty asm hides their loop invariance from the optimiser
+    asm volatile("" : "+v"(tok0));
+    const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
+    if constexpr (XB) {
+        constexpr int LPR = W / 8, RPI = 64 / LPR, NLD = 32 / RPI;
+        const int lrow = lane / LPR, lcol = 8 * (lane % LPR);
+        const unsigned ldb = (unsigned)p.ldx * 2u, cb = (unsigned)(k0 + lcol) * 2u;
+        u32x4 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const u32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(&xs[(RPI * i + lrow) * LD + lcol]) = v[i];
+    } else {
+        constexpr int LPR = W / 4, RPI = 64 / LPR, NLD = 32 / RPI;
+        const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
+        const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
+        constexpr int GB = NLD < 8 ? NLD : 8;     // loads in flight per batch (register budget)
+        if (p.film_g) {
+            constexpr int GF = GB < 4 ? GB : 4;
+            // FiLM group of a row: 32 consecutive rows cross at most one group boundary (film_group >= 32)
+            const int tb = min(tok0, last_tok);
+            const int g0 = tb / p.film_group, rem0 = tb - g0 * p.film_group;
+            const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g);
+            const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b);
+            const unsigned fldb = (unsigned)p.film_ld * 4u;
+#pragma unroll
+            for (int b0 = 0; b0 < NLD; b0 += GF) {
+                f32x4 v[GF], g[GF], b[GF];
+#pragma unroll
+                for (int i = 0; i < GF; ++i) {
+                    const int r = min(tok0 + lrow + RPI * (b0 + i), last_tok);
+                    v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)r * ldb + cb));
+                    const unsigned fo = (unsigned)(g0 + (rem0 + (r - tb) >= p.film_group ? 1 : 0)) * fldb + cb;
+                    g[i] = *reinterpret_cast<const f32x4*>(Gc + fo);
+                    b[i] = *reinterpret_cast<const f32x4*>(Bc + fo);
+                }
+#pragma unroll
+                for (int i = 0; i < GF; ++i) {
+                    const f32x4 m = g[i] * v[i] + b[i];
+                    u32x2 w = {pack2(m[0], m[1]), pack2(m[2], m[3])};
+                    *reinterpret_cast<u32x2*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = w;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads out of this one's registers
+            }
+        } else {
+#pragma unroll
+            for (int b0 = 0; b0 < NLD; b0 += GB) {
+                f32x4 v[GB];
+#pragma unroll
+                for (int i = 0; i < GB; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + i), last_tok) * ldb + cb));
+#pragma unroll
+                for (int i = 0; i < GB; ++i) {
+                    u32x2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
+                    *reinterpret_cast<u32x2*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// ---- resident: all N = 32*NT_RES accumulators in registers, K streamed in slices of KSL ------------------------
+// PRE: what the epilogue adds to the product, prefetched while the last slice is multiplied:
+//      0 nothing, 1 residual rows, 2 previous output (accumulate), 3 decided at run time (generic, branchy)
+enum { PRE_NONE = 0, PRE_RES = 1, PRE_ACC = 2, PRE_ANY = 3 };
+template <int NT_RES, int KSL, bool XB, int PRE>
+__global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
+    constexpr int N = 32 * NT_RES;
+    constexpr int WLD = KSL + 8;                       // bf16 per LDS row (weights and activations)
+    constexpr int PIECES = KSL / 8;
+    constexpr int WLOADS = (32 * PIECES + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const Ws = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
+    __bf16* const Xs = Ws + 2 * 32 * WLD;                                   // [4][32*WLD]
+    float* const Ps = reinterpret_cast<float*>(Xs + 4 * 32 * WLD);          // bias | gamma | beta  [3][N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
-    const long tok0 = (long)blockIdx.x * (4 * TOK) + wave * TOK;
-    const int ntiles = p.N / 32;
+    const int tok0 = (int)blockIdx.x * 128 + wave * 32;
+    const int last_tok = (int)p.M - 1;
     const int nks = p.K / KSL;
-    const int nchunks = nks * ntiles;
-    const long last_tok = p.M - 1;
-    const float ksd = p.drop.p > 0.f ? 1.f / (1.f - p.drop.p) : 1.f;
+    const int nchunks = nks * NT_RES;
+    __bf16* const xs = Xs + wave * 32 * WLD;
 
-    // ---- weight chunk pipeline: chunk (ks, nt) = 32 output features x KSL reduction elements ----------------
     u32x4 wreg[WLOADS];
     const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
     auto load_chunk = [&](int ks, int nt) {
@@ -76,8 +150,8 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            wreg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (row < 32) wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
+            if ((32 * PIECES) % 256 == 0 || row < 32)
+                wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -85,263 +159,290 @@ __global__ __launch_bounds__(256, (NT_RES == 0 ? 2 : 1)) void tlin_kernel(const 
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if (row < 32) *reinterpret_cast<u32x4*>(&Ws[buf][row * WLD + 8 * piece]) = wreg[i];
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
         }
     };
-    // next chunk after (ks, nt) in (ks outer, nt inner) order
-    auto next_of = [&](int ks, int nt, int& nks_, int& nnt_) {
-        nnt_ = nt + 1; nks_ = ks;
-        if (nnt_ == ntiles) { nnt_ = 0; nks_ = ks + 1; }
-    };
 
-    f32x16 acc[NACC][TT];
-    bf16x8 xf[TT][KSL / 16];
-
-    // staged rows of this lane (rows past the end re-read the last valid token: never stored) and their
-    // FiLM group, in 32-bit arithmetic, computed once.  One load instruction covers 64 reduction elements of
-    // RPI rows: fp32 -> 16 lanes x 16 B per row (4 rows), bf16 -> 8 lanes x 16 B per row (8 rows).
-    constexpr int RPI = XB ? 8 : 4;
-    constexpr int NLD = TOK / RPI;
-    const int lrow = XB ? (lane >> 3) : (lane >> 4);
-    const int lcol = XB ? 8 * (lane & 7) : 4 * (lane & 15);      // element offset inside the 64-wide window
-    int rtok[NLD], rgrp[NLD];
-    {
-        const int t0 = (int)tok0 + lrow, lt = (int)last_tok;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            rtok[i] = min(t0 + RPI * i, lt);
-            rgrp[i] = (!XB && p.film_g) ? rtok[i] / p.film_group : 0;
-        }
-    }
     load_chunk(0, 0);
-    store_chunk(0);
-    int chunk = 0;
-    for (int ks = 0; ks < nks; ++ks) {
-        // ---- stage this wave's X slice: HBM -> (fp32 -> bf16, FiLM) -> LDS slab -> B fragments --------
-#pragma unroll
-        for (int q4 = 0; q4 < KSL / 64; ++q4) {
-            const int kbase = ks * KSL + q4 * 64 + lcol;
-            if constexpr (XB) {
-                const __bf16* Xb = reinterpret_cast<const __bf16*>(p.X);
-                u32x4 v[NLD];
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const u32x4*>(Xb + (long)rtok[i] * p.ldx + kbase);
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(&Xs[wave][(i * RPI + lrow) * XLD + lcol]) = v[i];
-            } else {
-                const float* Xf = reinterpret_cast<const float*>(p.X);
-                f32x4 v[NLD];
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xf + (long)rtok[i] * p.ldx + kbase);
-                if (p.film_g) {
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) {
-                        const long fo = (long)rgrp[i] * p.film_ld + kbase;
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.film_g + fo);
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.film_b + fo);
-                        v[i] = g * v[i] + b;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    u32x2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
-                    *reinterpret_cast<u32x2*>(&Xs[wave][(i * RPI + lrow) * XLD + lcol]) = w;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < TT; ++t)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    xf[t][q4 * 4 + s] = *reinterpret_cast<const bf16x8*>(&Xs[wave][(t * 32 + c) * XLD + 16 * s + 8 * h]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();     // chunk `chunk` is in Ws[chunk & 1]
-
-        if constexpr (NT_RES > 0) {
-#pragma unroll
-            for (int nt = 0; nt < NT_RES; ++nt) {
-                const int buf = chunk & 1;
-                const bool more = chunk + 1 < nchunks;
-                if (more) { int a_, b_; next_of(ks, nt, a_, b_); load_chunk(a_, b_); }
-                if (ks == 0) {
-#pragma unroll
-                    for (int t = 0; t < TT; ++t)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[nt][t][i] = 0.f;
-                }
-                // weight fragments are fetched four k-steps at a time so the LDS latency is paid once per group
-#pragma unroll
-                for (int s4 = 0; s4 < KSL / 64; ++s4) {
-                    bf16x8 wf[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * (4 * s4 + u) + 8 * h]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int t = 0; t < TT; ++t)
-                            acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[t][4 * s4 + u], acc[nt][t], 0, 0, 0);
-                }
-                if (more) store_chunk(buf ^ 1);
-                __syncthreads();
-                ++chunk;
-            }
-        } else {
-            for (int nt = 0; nt < ntiles; ++nt) {
-                const int buf = chunk & 1;
-                const bool more = chunk + 1 < nchunks;
-                if (more) load_chunk(0, nt + 1);
-#pragma unroll
-                for (int t = 0; t < TT; ++t)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[0][t][i] = 0.f;
-#pragma unroll
-                for (int s4 = 0; s4 < KSL / 64; ++s4) {
-                    bf16x8 wf[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(&Ws[buf][c * WLD + 16 * (4 * s4 + u) + 8 * h]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int t = 0; t < TT; ++t)
-                            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[t][4 * s4 + u], acc[0][t], 0, 0, 0);
-                }
-                // ---- streamed epilogue: 32 features x TOK tokens -------------------------------------------
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    const long tok = tok0 + t * 32 + c;
-                    const bool valid = tok < p.M;
-                    const long tokc = valid ? tok : last_tok;
-                    const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
-                    const long yoff = yrow * p.ldy + nt * 32 + 4 * h;
-                    const long moff = tokc * p.ldref + nt * 32 + 4 * h;
-                    f32x4 mm[4], yy[4], bb[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        mm[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (p.mask_ref) {
-                            if (p.mask_bf16) {     // only the sign matters: expand the four bf16 to fp32 bit patterns
-                                const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.mask_ref) + moff + 8 * g);
-                                mm[g] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
-                                              __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
-                            } else {
-                                mm[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask_ref) + moff + 8 * g);
-                            }
-                        }
-                        yy[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if constexpr (!YB) {
-                            if (p.accumulate) yy[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(p.Y) + yoff + 8 * g);
-                        }
-                        bb[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nt * 32 + 8 * g + 4 * h;
-                        f32x4 v = {acc[0][t][4 * g], acc[0][t][4 * g + 1], acc[0][t][4 * g + 2], acc[0][t][4 * g + 3]};
-                        v += bb[g];
-                        if (p.act_relu) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        }
-                        if (p.drop.p > 0.f) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tokc * p.drop_ld + n + j, ksd);
-                        }
-                        if (p.mask_ref) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = mm[g][j] > 0.f ? v[j] * p.mask_scale : 0.f;
-                        }
-                        v += yy[g];
-                        if (valid) {
-                            if constexpr (YB) {
-                                u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-                                *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.Y) + yoff + 8 * g) = w;
-                            } else {
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff + 8 * g) = v;
-                            }
-                        }
-                    }
-                }
-                if (more) store_chunk(buf ^ 1);
-                __syncthreads();
-                ++chunk;
-            }
-        }
+    for (int i = tid; i < N; i += 256) {
+        Ps[i] = p.bias ? p.bias[i] : 0.f;
+        Ps[N + i] = p.ln_g ? p.ln_g[i] : 1.f;
+        Ps[2 * N + i] = p.ln_g ? p.ln_b[i] : 0.f;
     }
+    store_chunk(0);
 
-    if constexpr (NT_RES > 0) {
-        // ---- resident epilogue: bias, dropout, residual, LayerNorm over the N = 32*NT_RES features ----------
-        constexpr int t = 0;                         // TOK == 32 in resident mode
-        const long tok = tok0 + c;
-        const bool valid = tok < p.M;
-        const long tokc = valid ? tok : last_tok;        // clamped row: loads are unconditional (batched, no exec branches)
-        const long yrow = p.y_row_group ? tokc + tokc / p.y_row_group + 1 : tokc;
-        const float* resp = p.res ? p.res + (tokc % p.res_rows) * p.ldres : nullptr;
-        float* yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy;
-        float sum = 0.f;
+    // epilogue row of this lane.  Rows past the end are clamped to the last token: such lanes recompute that row
+    // bit for bit, so their stores are harmless duplicates - except when accumulating, where stores are predicated.
+    const int tok = tok0 + c;
+    const bool valid = tok <= last_tok;
+    const int tokc = valid ? tok : last_tok;
+    const long yrow = p.y_row_group ? (long)tokc + tokc / p.y_row_group + 1 : (long)tokc;
+    float* const yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy;
+    const float* const resp = p.res ? p.res + (long)(tokc % (int)p.res_rows) * p.ldres : nullptr;
+    constexpr bool PRED = PRE >= PRE_ACC;
+
+    f32x16 acc[NT_RES];
+    bf16x8 xf[KSL / 16];
+    f32x4 pre[NT_RES][4];
+    // first half with the last activation slice, second half from the middle of the last MFMA pass
+    auto load_pre = [&](int nt0, int nt1) {
 #pragma unroll
-        for (int nt = 0; nt < NT_RES; ++nt) {
-            f32x4 rr[4], yy[4], bb[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {                // issue the tile's loads together
-                const int n = nt * 32 + 8 * g + 4 * h;
-                rr[g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                yy[g] = p.accumulate ? *reinterpret_cast<const f32x4*>(yb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                bb[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int nt = nt0; nt < nt1; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nt * 32 + 8 * g + 4 * h;
-                f32x4 v = {acc[nt][t][4 * g], acc[nt][t][4 * g + 1], acc[nt][t][4 * g + 2], acc[nt][t][4 * g + 3]};
-                v += bb[g];
-                if (p.drop.p > 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, (uint64_t)tokc * p.drop_ld + n + j, ksd);
+                if constexpr (PRE == PRE_RES) pre[nt][g] = *reinterpret_cast<const f32x4*>(resp + n);
+                if constexpr (PRE == PRE_ACC) pre[nt][g] = *reinterpret_cast<const f32x4*>(yb + n);
+                if constexpr (PRE == PRE_ANY) {
+                    pre[nt][g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.accumulate) pre[nt][g] += *reinterpret_cast<const f32x4*>(yb + n);
                 }
-                v += rr[g] + yy[g];
-                if (valid) *reinterpret_cast<f32x4*>(yb + n) = v;
+            }
+    };
+
+    int chunk = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        stage_x<KSL, WLD, XB>(p, xs, tok0, last_tok, ks * KSL, lane);
+        if constexpr (PRE != PRE_NONE) {
+            if (ks == nks - 1) load_pre(0, NT_RES / 2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KSL / 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(&xs[c * WLD + 16 * s + 8 * h]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();     // chunk `chunk` is in Ws[chunk & 1] (and Ps on the first pass)
+
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt) {
+            const int buf = chunk & 1;
+            const bool more = chunk + 1 < nchunks;
+            if (more) load_chunk(nt + 1 == NT_RES ? ks + 1 : ks, nt + 1 == NT_RES ? 0 : nt + 1);
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            }
+            if constexpr (PRE != PRE_NONE) {
+                if (nt == NT_RES / 2 && ks == nks - 1) load_pre(NT_RES / 2, NT_RES);
+            }
+            const __bf16* wsb = Ws + buf * 32 * WLD + c * WLD + 8 * h;
+#pragma unroll
+            for (int s4 = 0; s4 < KSL / 64; ++s4) {
+                bf16x8 wf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc[nt], 0, 0, 0);
+            }
+            if (more) store_chunk(buf ^ 1);
+            __syncthreads();
+            ++chunk;
+        }
+    }
+
+    // ---- epilogue: bias, dropout, residual / accumulate, LayerNorm over the N features; stores only ----------
+    float sum = 0.f;
+    auto epilogue = [&](auto drop_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value;
+        const float ksd = DROP ? 1.f / (1.f - p.drop.p) : 1.f;
+        const uint64_t dbase = (uint64_t)tokc * p.drop_ld;
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nt * 32 + 8 * g + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[n]);
+                f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                v += bb;
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, dbase + n + j, ksd);
+                }
+                if constexpr (PRE != PRE_NONE) v += pre[nt][g];
+                if (!PRED || valid) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[nt][t][4 * g + j] = v[j];
+                    acc[nt][4 * g + j] = v[j];
                     sum += v[j];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);     // one feature tile at a time: LDS reads are not hoisted across tiles
         }
-        if (p.ln_g) {
-            const float invn = 1.f / (float)(32 * NT_RES);
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * invn;
-            float var = 0.f;
+    };
+    if (p.drop.p > 0.f) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+
+    if (p.ln_g) {
+        const float invn = 1.f / (float)N;
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * invn;
+        float var = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT_RES; ++nt)
+        for (int nt = 0; nt < NT_RES; ++nt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float d = acc[nt][t][i] - mean;
-                    var += d * d;
-                }
-            var += __shfl_xor(var, 32, 64);
-            const float rstd = rsqrtf(var * invn + LN_EPS);
-            if (valid) {
+            for (int i = 0; i < 16; ++i) {
+                const float d = acc[nt][i] - mean;
+                var += d * d;
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * invn + LN_EPS);
+        float* const lb = p.ln_y + (long)tokc * p.ldy;
 #pragma unroll
-                for (int nt = 0; nt < NT_RES; ++nt)
+        for (int nt = 0; nt < NT_RES; ++nt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nt * 32 + 8 * g + 4 * h;
-                        const f32x4 gg_ = *reinterpret_cast<const f32x4*>(p.ln_g + n);
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + n);
-                        f32x4 y;
+            for (int g = 0; g < 4; ++g) {
+                const int n = nt * 32 + 8 * g + 4 * h;
+                const f32x4 gg_ = *reinterpret_cast<const f32x4*>(&Ps[N + n]);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[2 * N + n]);
+                f32x4 y;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = (acc[nt][t][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
-                        *reinterpret_cast<f32x4*>(p.ln_y + tok * p.ldy + n) = y;
-                    }
-                if (h == 0) {
-                    p.ln_stats[2 * tok] = mean;
-                    p.ln_stats[2 * tok + 1] = rstd;
+                for (int j = 0; j < 4; ++j) y[j] = (acc[nt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
+                if (!PRED || valid) *reinterpret_cast<f32x4*>(lb + n) = y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (h == 0 && valid) {
+            p.ln_stats[2 * (long)tok] = mean;
+            p.ln_stats[2 * (long)tok + 1] = rstd;
+        }
+    }
+}
+
+// ---- stream: K <= 256 register-resident, N streamed 32 features at a time ----------------------------------------
+// EPI: 0 bias (+ReLU), 1 bias (+ReLU) + dropout, 2 bias + sign mask of a reference tensor, 3 decided at run time
+enum { EPI_BIAS = 0, EPI_DROP = 1, EPI_MASK = 2, EPI_ANY = 3 };
+template <int KSL, bool XB, bool YB, int EPI>
+__global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
+    constexpr int XW = KSL < 128 ? KSL : 128;          // staging window (bounds LDS so two workgroups fit a CU)
+    constexpr int XLDW = XW + 8;
+    constexpr int WLD = KSL + 8;
+    constexpr int PIECES = KSL / 8;
+    constexpr int WLOADS = (32 * PIECES + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const Ws = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
+    __bf16* const Xs = Ws + 2 * 32 * WLD;                                   // [4][32*XLDW]
+    float* const Ps = reinterpret_cast<float*>(Xs + 4 * 32 * XLDW);         // bias [N]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int tok0 = (int)blockIdx.x * 128 + wave * 32;
+    const int last_tok = (int)p.M - 1;
+    const int ntiles = p.N / 32;
+    __bf16* const xs = Xs + wave * 32 * XLDW;
+
+    u32x4 wreg[WLOADS];
+    const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+    auto load_chunk = [&](int nt) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / PIECES, piece = f % PIECES;
+            if ((32 * PIECES) % 256 == 0 || row < 32) wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + 8 * piece);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / PIECES, piece = f % PIECES;
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
+        }
+    };
+
+    load_chunk(0);
+    for (int i = tid; i < p.N; i += 256) Ps[i] = p.bias ? p.bias[i] : 0.f;
+    store_chunk(0);
+
+    bf16x8 xf[KSL / 16];
+#pragma unroll
+    for (int q = 0; q < KSL / XW; ++q) {
+        stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < XW / 16; ++s) xf[q * (XW / 16) + s] = *reinterpret_cast<const bf16x8*>(&xs[c * XLDW + 16 * s + 8 * h]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    const int tok = tok0 + c;
+    const bool valid = tok <= last_tok;
+    const int tokc = valid ? tok : last_tok;          // clamped lanes recompute the last row bit for bit (see above)
+    const long yrow = p.y_row_group ? (long)tokc + tokc / p.y_row_group + 1 : (long)tokc;
+    const long ybase = yrow * p.ldy + 4 * h;
+    const long mbase = (long)tokc * p.ldref + 4 * h;
+    const uint64_t dbase = (uint64_t)tokc * p.drop_ld;
+    const float floor_ = p.act_relu ? 0.f : -__builtin_inff();
+    const bool drop_on = EPI == EPI_DROP || (EPI == EPI_ANY && p.drop.p > 0.f);
+    const bool mask_on = EPI == EPI_MASK || (EPI == EPI_ANY && p.mask_ref != nullptr);
+    const bool acc_on = EPI == EPI_ANY && !YB && p.accumulate;
+    const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
+    constexpr bool PRED = EPI == EPI_ANY;
+
+    for (int nt = 0; nt < ntiles; ++nt) {
+        const int buf = nt & 1;
+        const bool more = nt + 1 < ntiles;
+        if (more) load_chunk(nt + 1);
+        // operands of this tile's epilogue are requested before the MFMA chain
+        f32x4 mm[4], yy[4];
+        if (mask_on) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (p.mask_bf16) {     // only the sign matters: expand the four bf16 to fp32 bit patterns
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.mask_ref) + mbase + nt * 32 + 8 * g);
+                    mm[g] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                                  __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                } else {
+                    mm[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask_ref) + mbase + nt * 32 + 8 * g);
                 }
             }
         }
+        if (acc_on) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) yy[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + 8 * g);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const __bf16* wsb = Ws + buf * 32 * WLD + c * WLD + 8 * h;
+#pragma unroll
+        for (int s4 = 0; s4 < KSL / 64; ++s4) {
+            bf16x8 wf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + 4 * h;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[n]);
+            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            v += bb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_);
+            if (drop_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, dbase + n + j, ksd);
+            }
+            if (mask_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = mm[g][j] > 0.f ? v[j] * p.mask_scale : 0.f;
+            }
+            if (acc_on) v += yy[g];
+            if (!PRED || valid) {
+                if constexpr (YB) {
+                    u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.Y) + ybase + nt * 32 + 8 * g) = w;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + 8 * g) = v;
+                }
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
     }
 }
 
@@ -358,20 +459,55 @@ __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ 
     }
 }
 
-template <int TOK, int NT_RES, int KSL, bool XB, bool YB>
-int launch(const TlinP& p, hipStream_t st) {
-    const long blocks = (p.M + 4 * TOK - 1) / (4 * TOK);
-    hipLaunchKernelGGL((tlin_kernel<TOK, NT_RES, KSL, XB, YB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+template <int NT_RES, int KSL, bool XB, int PRE>
+int launch_res(const TlinP& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)6 * 32 * (KSL + 8) * 2 + (size_t)3 * 32 * NT_RES * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_res_kernel<NT_RES, KSL, XB, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const long blocks = (p.M + 127) / 128;
+    hipLaunchKernelGGL((tlin_res_kernel<NT_RES, KSL, XB, PRE>), dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int TOK, int NT_RES, int KSL>
-int launch_t(const TlinP& p, hipStream_t st) {
-    if (NT_RES == 0) {
-        if (p.x_bf16) return p.y_bf16 ? launch<TOK, NT_RES, KSL, true, true>(p, st) : launch<TOK, NT_RES, KSL, true, false>(p, st);
-        return p.y_bf16 ? launch<TOK, NT_RES, KSL, false, true>(p, st) : launch<TOK, NT_RES, KSL, false, false>(p, st);
+constexpr size_t STREAM_SMEM_MAX = 160 * 1024;
+template <int KSL, bool XB, bool YB, int EPI>
+int launch_str(const TlinP& p, hipStream_t st) {
+    constexpr int XW = KSL < 128 ? KSL : 128;
+    const size_t smem = (size_t)2 * 32 * (KSL + 8) * 2 + (size_t)4 * 32 * (XW + 8) * 2 + (size_t)p.N * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_str_kernel<KSL, XB, YB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STREAM_SMEM_MAX));
+        attr_set = true;
     }
-    return p.x_bf16 ? launch<TOK, NT_RES, KSL, true, false>(p, st) : launch<TOK, NT_RES, KSL, false, false>(p, st);
+    const long blocks = (p.M + 127) / 128;
+    hipLaunchKernelGGL((tlin_str_kernel<KSL, XB, YB, EPI>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int KSL, int EPI>
+int launch_str_t(const TlinP& p, hipStream_t st) {
+    if (p.x_bf16) return p.y_bf16 ? launch_str<KSL, true, true, EPI>(p, st) : launch_str<KSL, true, false, EPI>(p, st);
+    return p.y_bf16 ? launch_str<KSL, false, true, EPI>(p, st) : launch_str<KSL, false, false, EPI>(p, st);
+}
+// the specialised epilogues exist for the production width (K = 256); other widths take the run-time one
+int launch_str_256(const TlinP& p, hipStream_t st) {
+    if (p.accumulate || (p.mask_ref && p.drop.p > 0.f)) return launch_str_t<256, EPI_ANY>(p, st);
+    if (p.mask_ref) return launch_str_t<256, EPI_MASK>(p, st);
+    if (p.drop.p > 0.f) return launch_str_t<256, EPI_DROP>(p, st);
+    return launch_str_t<256, EPI_BIAS>(p, st);
+}
+template <int NT_RES, int KSL, int PRE>
+int launch_res_t(const TlinP& p, hipStream_t st) {
+    return p.x_bf16 ? launch_res<NT_RES, KSL, true, PRE>(p, st) : launch_res<NT_RES, KSL, false, PRE>(p, st);
+}
+int launch_res_256(const TlinP& p, hipStream_t st) {
+    if (p.res && p.accumulate) return launch_res_t<8, 256, PRE_ANY>(p, st);
+    if (p.res) return launch_res_t<8, 256, PRE_RES>(p, st);
+    if (p.accumulate) return launch_res_t<8, 256, PRE_ACC>(p, st);
+    return launch_res_t<8, 256, PRE_NONE>(p, st);
 }
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 inline bool needs_resident(const TlinP& p) { return p.ln_g || p.res || !(p.K == 64 || p.K == 128 || p.K == 256); }
@@ -384,12 +520,12 @@ bool tlin_supported(const TlinP& p) {
     if (p.N % 32 || p.K % 64) return false;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % (p.x_bf16 ? 8 : 4) || p.ldy % 4 || p.ldw % 8) return false;
     if (p.bias && !al16(p.bias)) return false;
-    if (p.film_g && (p.x_bf16 || !al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group <= 0)) return false;
+    if (p.film_g && (p.x_bf16 || !al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group < 32)) return false;
     if (p.mask_ref && (!al16(p.mask_ref) || p.ldref % 4)) return false;
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
     if (p.y_bf16 && p.accumulate) return false;
-    if (!needs_resident(p)) return true;
+    if (!needs_resident(p)) return (size_t)p.N * 4 <= 64 * 1024;     // bias vector in LDS
     if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue
     if (p.N == 256) return p.K % 256 == 0;
     if (p.N == 128) return p.K % 128 == 0;
@@ -400,13 +536,13 @@ bool tlin_supported(const TlinP& p) {
 int tlin(const TlinP& p, hipStream_t st) {
     GG_REQUIRE(tlin_supported(p), "tlin: unsupported shape / alignment");
     if (!needs_resident(p)) {
-        if (p.K == 256) return launch_t<32, 0, 256>(p, st);
-        if (p.K == 128) return launch_t<32, 0, 128>(p, st);
-        return launch_t<32, 0, 64>(p, st);
+        if (p.K == 256) return launch_str_256(p, st);
+        if (p.K == 128) return launch_str_t<128, EPI_ANY>(p, st);
+        return launch_str_t<64, EPI_ANY>(p, st);
     }
-    if (p.N == 256) return launch_t<32, 8, 256>(p, st);
-    if (p.N == 128) return launch_t<32, 4, 128>(p, st);
-    return launch_t<32, 2, 64>(p, st);
+    if (p.N == 256) return launch_res_256(p, st);
+    if (p.N == 128) return launch_res_t<4, 128, PRE_ANY>(p, st);
+    return launch_res_t<2, 64, PRE_ANY>(p, st);
 }
 
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {

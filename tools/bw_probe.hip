@@ -36,6 +36,29 @@ __global__ void wr_tile4B(float* Y, long M, int N) {
     const long tiles_n = N / 32; const long tm = w / tiles_n, tn = w % tiles_n;   // a wave owns a 32x32 tile
     for (int i = 0; i < 16; ++i) { long r = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h; if (r < M) Y[r * N + tn * 32 + c] = 1.f * i; }
 }
+
+// (f) tlin resident out_proj traffic shape with every load of a 32-token wave tile issued up front:
+//     X bf16 [M][256] (row windows), residual fp32 [M][256] lane-owns-row, two fp32 outputs lane-owns-row.
+//     lds bytes force the occupancy (1 block / CU at > 80 KB).
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mix_probe(const unsigned short* X, const float* R, float* Y0, float* Y1, long M) {
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long t0 = w * 32; if (t0 >= M) return;
+    u4 xv[16]; f4 rr[32];
+    for (int i = 0; i < 16; ++i) { long r = t0 + 2 * i + (lane >> 5); xv[i] = *(const u4*)(X + r * 256 + 8 * (lane & 31)); }
+    const long tok = t0 + c;
+    for (int i = 0; i < 32; ++i) rr[i] = *(const f4*)(R + tok * 256 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h);
+    unsigned s = 0; for (int i = 0; i < 16; ++i) s += xv[i][0] ^ xv[i][1] ^ xv[i][2] ^ xv[i][3];
+    if (smem && s == 0x12345u) smem[lane] = 1;
+    const float sf = (float)(s & 1);
+    for (int i = 0; i < 32; ++i) { f4 v = rr[i] + sf; *(f4*)(Y0 + tok * 256 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h) = v; }
+    for (int i = 0; i < 32; ++i) { f4 v = rr[i] * 2.f + sf; *(f4*)(Y1 + tok * 256 + (i >> 2) * 32 + 8 * (i & 3) + 4 * h) = v; }
+}
+// (g) plain grid-stride copy, 16 B per lane
+__global__ void copy_probe(const f4* a, f4* b, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize(); hipEventRecord(a); for (int i = 0; i < 10; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
@@ -60,6 +83,24 @@ int main() {
         const long w2 = (M / 32) * (N / 32); const int b2 = (int)((w2 + 3) / 4);
         t = timeit([&] { wr_tile4B<<<b2, 256>>>(Y, M, N); });
         printf("write 32x32 tile 4B  N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 4.0 / t / 1e6);
+    }
+    {
+        unsigned short* Xb = (unsigned short*)X; float* R = X + M * 128; float* Y1 = Y + M * 256;
+        const long wv = M / 32; const int bl = (int)((wv + 3) / 4);
+        for (int lds : {0, 40000, 60000, 100000}) {
+            hipFuncSetAttribute((const void*)mix_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            float t = timeit([&] { mix_probe<<<bl, 256, lds>>>(Xb, R, Y, Y1, M); });
+            printf("mix out_proj shape lds=%6d: %7.1f us %6.2f TB/s\n", lds, t, M * 3584.0 / t / 1e6);
+        }
+        for (long MM : {65792L, 131584L}) {
+            const int b2 = (int)((MM / 32 + 3) / 4);
+            hipFuncSetAttribute((const void*)mix_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 100000);
+            float t = timeit([&] { mix_probe<<<b2, 256, 100000>>>(Xb, R, Y, Y1, MM); });
+            printf("mix out_proj shape M=%ld lds=100000: %7.1f us %6.2f TB/s\n", MM, t, MM * 3584.0 / t / 1e6);
+        }
+        const long n = M * 256;   // 16-B elements: 808 MB each way
+        float t = timeit([&] { copy_probe<<<256 * 8, 256>>>((const f4*)X, (f4*)Y, n); });
+        printf("copy 2x%.0f MB: %7.1f us %6.2f TB/s (read+write)\n", n * 16.0 / 1e6, t, 2.0 * n * 16 / t / 1e6);
     }
     return 0;
 }
