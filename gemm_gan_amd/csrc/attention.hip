@@ -18,22 +18,11 @@
 // Dropout uses the same counter hash and the same element index ((n*nh+h)*S+q)*S+key as the unfused
 // path (kernels.hip), so both paths draw identical masks.
 #include "kernels.h"
+#include "drop_rng.h"
 
 namespace gg {
 
 namespace {
-
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return h;
-}
-__device__ __forceinline__ float drop_factor(const DropKey& k, uint64_t i, float keep_scale) {
-    uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
-    uint32_t h = fmix32(lo * 0x9E3779B1u + k.k0);
-    h = fmix32(h ^ k.k1 ^ (hi * 0x7F4A7C15u));
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    return u >= k.p ? keep_scale : 0.f;
-}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -205,7 +194,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
-        const uint64_t rowbase = ((uint64_t)blockIdx.x * S + (uint64_t)q) * S;
+        // dropout stream state of this lane's row at its first key pair (drop_rng.h: linear in the pair index)
+        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 s16;
 #pragma unroll
@@ -240,9 +230,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
-            if (drop.p > 0.f) {
+            if (drop.p > 0.f) {     // registers 4g..4g+3 hold 4 consecutive keys: two pair hashes
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s16[i] *= drop_factor(drop, rowbase + (uint64_t)(kt * 32 + acc_row(i, h)), 1.f);
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    s16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? s16[4 * g + 0] : 0.f;
+                    s16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? s16[4 * g + 1] : 0.f;
+                    s16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? s16[4 * g + 2] : 0.f;
+                    s16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? s16[4 * g + 3] : 0.f;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
-        const uint64_t rowbase = ((uint64_t)blockIdx.x * S + (uint64_t)q) * S;
+        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 s16, dp16;
 #pragma unroll
@@ -361,13 +358,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
                 s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
                 dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
             }
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                    dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                    dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                    dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kt * 32 + acc_row(i, h);
                 const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
-                float dp = dp16[i];
-                if (drop.p > 0.f) dp *= drop_factor(drop, rowbase + (uint64_t)key, ks);
-                s16[i] = p * (dp - dl) * scale;
+                s16[i] = p * (dp16[i] - dl) * scale;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
             float pd = 0.f, ds = 0.f;
             if (kvalid && qq < S) {
                 const float p = fast_exp2(s16[i] * sc - Ls[wave][row]);
-                const float kfac = drop.p > 0.f ? drop_factor(drop, ((uint64_t)nhid * S + (uint64_t)qq) * S + (uint64_t)key, ks) : 1.f;
+                const float kfac = drop.p > 0.f ? drop_factor(drop, ((uint64_t)nhid * S + (uint64_t)qq) * (uint64_t)drop_attn_ld(S) + (uint64_t)key, ks) : 1.f;
                 pd = p * kfac;
                 ds = p * (dp16[i] * kfac - Dl[wave][row]) * scale;
             }

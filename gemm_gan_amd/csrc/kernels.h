@@ -8,7 +8,8 @@ namespace gg {
 // counter-hash dropout stream: element i of site `site` in forward call `call` (see kernels.hip)
 struct DropKey {
     float p = 0.f;          // drop probability; 0 => disabled
-    uint32_t k0 = 0, k1 = 0;
+    uint32_t k0 = 0;        // 32-bit mix of (seed, site, call)
+    uint32_t thr = 0;       // round(p * 65536): element kept iff its 16-bit uniform >= thr
 };
 DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call);
 
@@ -123,6 +124,7 @@ struct TlinP {
     int accumulate = 0;                             // y += previous content
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
+    int dbg = 0;                                    // timing experiments only (GG_TLIN_DBG): 1 no stores, 2 no MFMA, 4 no weight loads, 8 no X loads
 };
 bool tlin_supported(const TlinP& p);
 int tlin(const TlinP& p, hipStream_t st);

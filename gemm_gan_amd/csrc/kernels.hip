@@ -3,6 +3,7 @@
 // owned by one 64-lane wave so all reductions are wave shuffles (no LDS round trips, no atomics
 // except the cross-row parameter-gradient sums).
 #include "kernels.h"
+#include "drop_rng.h"
 
 namespace gg {
 
@@ -26,21 +27,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- dropout stream -----------------------------------------------------------------------------
-// keep(i) for element i of a (seed, site, call) stream: two rounds of the murmur3 32-bit finaliser
-// over the element counter, keyed per stream.  Counter based => the backward pass regenerates the
-// identical mask from (key, i) and no mask tensor is ever stored.
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return h;
-}
-__device__ __forceinline__ float drop_factor(const DropKey& k, uint64_t i, float keep_scale) {
-    uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
-    uint32_t h = fmix32(lo * 0x9E3779B1u + k.k0);
-    h = fmix32(h ^ k.k1 ^ (hi * 0x7F4A7C15u));
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    return u >= k.p ? keep_scale : 0.f;
-}
+// ---- dropout stream: drop_rng.h ---------------------------------------------------------------
 }  // namespace
 
 DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call) {
@@ -52,8 +39,9 @@ DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call) {
     };
     uint64_t a = mix(seed ^ (0x9E3779B97F4A7C15ULL * (site + 1)));
     uint64_t b = mix(a ^ (0xD1B54A32D192ED03ULL * ((uint64_t)call + 1)));
-    k.k0 = (uint32_t)b;
-    k.k1 = (uint32_t)(b >> 32);
+    k.k0 = (uint32_t)b ^ (uint32_t)(b >> 32);
+    const long t = lrintf(p * 65536.f);
+    k.thr = (uint32_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
     return k;
 }
 
@@ -234,7 +222,7 @@ __global__ __launch_bounds__(TPB) void softmax_rows_k(float* S, float* Pd, long 
         for (int c = lane; c < cols; c += 64) {
             const float p = buf[wave][c] * inv;
             s[c] = p;
-            if (Pd) Pd[row * cols + c] = p * drop_factor(drop, (uint64_t)row * cols + c, ks);
+            if (Pd) Pd[row * cols + c] = p * drop_factor(drop, (uint64_t)row * drop_attn_ld(cols) + c, ks);
         }
     }
 }
@@ -255,7 +243,7 @@ __global__ __launch_bounds__(TPB) void softmax_bwd_rows_k(float* dP, const float
         float dot = 0.f;
         for (int c = lane; c < cols; c += 64) {
             float g = d[c];
-            if (drop.p > 0.f) g *= drop_factor(drop, (uint64_t)row * cols + c, ks);
+            if (drop.p > 0.f) g *= drop_factor(drop, (uint64_t)row * drop_attn_ld(cols) + c, ks);
             buf[wave][c] = g;
             dot += g * p[c];
         }
@@ -434,8 +422,10 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
                 *reinterpret_cast<f32x4*>(dr + row * E + c) = v;
                 f32x4 vb = v;
                 if (drop.p > 0.f) {
+                    float f[4];     // E % 4 == 0 and c % 4 == 0: the four elements are two aligned pairs
+                    drop_factor4(drop, (uint64_t)row * E + c, ks, f);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) vb[q] = v[q] * drop_factor(drop, (uint64_t)row * E + c + q, ks);
+                    for (int q = 0; q < 4; ++q) vb[q] = v[q] * f[q];
                 }
                 if (dres) {
                     if (dres_bf16) {

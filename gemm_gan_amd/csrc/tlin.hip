@@ -18,23 +18,13 @@
 //   resident (NT_RES = N/32 <= 8): all N accumulators resident, K streamed in slices of 256, TOK = 32;
 //                                  enables the fused residual + LayerNorm epilogue (N = E).
 #include "kernels.h"
+#include "drop_rng.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace gg {
 
 namespace {
-
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return h;
-}
-__device__ __forceinline__ float drop_factor(const DropKey& k, uint64_t i, float keep_scale) {
-    uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
-    uint32_t h = fmix32(lo * 0x9E3779B1u + k.k0);
-    h = fmix32(h ^ k.k1 ^ (hi * 0x7F4A7C15u));
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    return u >= k.p ? keep_scale : 0.f;
-}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -54,16 +44,22 @@ constexpr float LN_EPS = 1e-5f;
 // traffic shape with batched loads at one workgroup per CU: 4.5 - 5.1 TB/s (tools/bw_probe.hip, mix_probe).
 // ---------------------------------------------------------------------------------------------------------------
 
+// Feature order inside a 32-feature chunk.  The MFMA writes output row (i&3) + 8*(i>>2) + 4*h to register i of lane
+// half h; feeding A-operand row r with weight row 16*((r>>2)&1) + (r&3) + 4*(r>>3) makes register i of half h hold
+// feature 16*h + i: every lane owns 16 CONSECUTIVE features of its token (64 B fp32 / 32 B bf16 per chunk), so all
+// epilogue loads and stores are 16-byte accesses to contiguous runs (8-byte pieces measured 3.1 TB/s, these 5.7+).
+__device__ __forceinline__ int a_row_of_lane(int r) { return 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3); }
+
 // stages rows [tok0, tok0+32) x [k0, k0+W) of X (fp32 or bf16, FiLM optional) as bf16 into the wave-private slab xs
 // (row stride LD elements).  GB bounds the loads in flight (registers): all of them for bf16, halves for fp32.
-template <int W, int LD, bool XB>
+template <int W, int LD, bool XB, int ROWS = 32>
 __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, int last_tok, int k0, int lane) {
     // the row offsets are recomputed per call (32-bit, a few VALU ops) instead of living in registers across the
     // K loop: the empty asm hides their loop invariance from the optimiser
     asm volatile("" : "+v"(tok0));
     const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
     if constexpr (XB) {
-        constexpr int LPR = W / 8, RPI = 64 / LPR, NLD = 32 / RPI;
+        constexpr int LPR = W / 8, RPI = 64 / LPR, NLD = ROWS / RPI;
         const int lrow = lane / LPR, lcol = 8 * (lane % LPR);
         const unsigned ldb = (unsigned)p.ldx * 2u, cb = (unsigned)(k0 + lcol) * 2u;
         u32x4 v[NLD];
@@ -72,7 +68,7 @@ __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, in
 #pragma unroll
         for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(&xs[(RPI * i + lrow) * LD + lcol]) = v[i];
     } else {
-        constexpr int LPR = W / 4, RPI = 64 / LPR, NLD = 32 / RPI;
+        constexpr int LPR = W / 4, RPI = 64 / LPR, NLD = ROWS / RPI;
         const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
         const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
         constexpr int GB = NLD < 8 ? NLD : 8;     // loads in flight per batch (register budget)
@@ -143,27 +139,31 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
     const int nchunks = nks * NT_RES;
     __bf16* const xs = Xs + wave * 32 * WLD;
 
-    u32x4 wreg[WLOADS];
+    // weight chunks (32 output features x KSL) travel L2 -> registers -> LDS two chunks ahead of their use: the
+    // loads of chunk c+2 are issued when chunk c is multiplied and written to LDS one chunk later, so an L2 round
+    // trip is covered by two MFMA passes.  Chunk c uses register set and LDS buffer c & 1 (NT_RES is even).
+    u32x4 wreg[2][WLOADS];
     const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
-    auto load_chunk = [&](int ks, int nt) {
+    auto load_chunk = [&](int set, int ks, int nt) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
             if ((32 * PIECES) % 256 == 0 || row < 32)
-                wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
+                wreg[set][i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int set) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[set * 32 * WLD + row * WLD + 8 * piece]) = wreg[set][i];
         }
     };
 
-    load_chunk(0, 0);
+    load_chunk(0, 0, 0);
+    load_chunk(1, 0, 1);
     for (int i = tid; i < N; i += 256) {
         Ps[i] = p.bias ? p.bias[i] : 0.f;
         Ps[N + i] = p.ln_g ? p.ln_g[i] : 1.f;
@@ -202,9 +202,9 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
-        stage_x<KSL, WLD, XB>(p, xs, tok0, last_tok, ks * KSL, lane);
+        if (!(p.dbg & 8)) stage_x<KSL, WLD, XB>(p, xs, tok0, last_tok, ks * KSL, lane);
         if constexpr (PRE != PRE_NONE) {
-            if (ks == nks - 1) load_pre(0, NT_RES / 2);
+            if (ks == nks - 1 && !(p.dbg & 16)) load_pre(0, NT_RES / 2);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -216,15 +216,14 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 
 #pragma unroll
         for (int nt = 0; nt < NT_RES; ++nt) {
-            const int buf = chunk & 1;
-            const bool more = chunk + 1 < nchunks;
-            if (more) load_chunk(nt + 1 == NT_RES ? ks + 1 : ks, nt + 1 == NT_RES ? 0 : nt + 1);
+            const int buf = nt & 1;      // compile-time after unrolling
+            if (chunk + 2 < nchunks && !(p.dbg & 4)) load_chunk(buf, nt + 2 >= NT_RES ? ks + 1 : ks, (nt + 2) % NT_RES);
             if (ks == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             }
             if constexpr (PRE != PRE_NONE) {
-                if (nt == NT_RES / 2 && ks == nks - 1) load_pre(NT_RES / 2, NT_RES);
+                if (nt == NT_RES / 2 && ks == nks - 1 && !(p.dbg & 16)) load_pre(NT_RES / 2, NT_RES);
             }
             const __bf16* wsb = Ws + buf * 32 * WLD + c * WLD + 8 * h;
 #pragma unroll
@@ -232,10 +231,12 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 bf16x8 wf[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
+                if (!(p.dbg & 2)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc[nt], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc[nt], 0, 0, 0);
+                }
             }
-            if (more) store_chunk(buf ^ 1);
+            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
             __syncthreads();
             ++chunk;
         }
@@ -256,11 +257,13 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
                 v += bb;
                 if constexpr (DROP) {
+                    float f[4];
+                    drop_factor4(p.drop, dbase + n, ksd, f);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, dbase + n + j, ksd);
+                    for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
                 if constexpr (PRE != PRE_NONE) v += pre[nt][g];
-                if (!PRED || valid) *reinterpret_cast<f32x4*>(yb + n) = v;
+                if ((!PRED || valid) && !((p.dbg & 1) && v[0] != 1234.5f)) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[nt][4 * g + j] = v[j];
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
             __builtin_amdgcn_sched_barrier(0);     // one feature tile at a time: LDS reads are not hoisted across tiles
         }
     };
-    if (p.drop.p > 0.f) epilogue(std::true_type{});
+    if (p.drop.p > 0.f && !(p.dbg & 32)) epilogue(std::true_type{});
     else epilogue(std::false_type{});
 
     if (p.ln_g) {
@@ -298,11 +301,193 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 f32x4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = (acc[nt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
-                if (!PRED || valid) *reinterpret_cast<f32x4*>(lb + n) = y;
+                if ((!PRED || valid) && !((p.dbg & 1) && y[0] != 1234.5f)) *reinterpret_cast<f32x4*>(lb + n) = y;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (h == 0 && valid) {
+            p.ln_stats[2 * (long)tok] = mean;
+            p.ln_stats[2 * (long)tok + 1] = rstd;
+        }
+    }
+}
+
+// ---- resident, 16-token wave tiles (v_mfma_f32_16x16x32_bf16) ----------------------------------------------------
+// Same contract as tlin_res_kernel, half the registers and LDS per workgroup (64 tokens), so TWO workgroups share a
+// CU: while one multiplies / normalises, the other's activation and residual loads are in flight.  The accumulator
+// tile is 16 features x 16 tokens: lane = (token lane&15, feature quad lane>>4), four consecutive features per
+// register quad, so one store instruction writes 16 rows x 64 contiguous bytes.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int NT_RES, int KSL, bool XB, int PRE>
+__global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
+    constexpr int N = 32 * NT_RES;
+    constexpr int NF = 2 * NT_RES;                     // 16-feature tiles
+    constexpr int WLD = KSL + 8;
+    constexpr int PIECES = KSL / 8;
+    constexpr int WLOADS = (32 * PIECES + 255) / 256;
+    constexpr int KS32 = KSL / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const Ws = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
+    __bf16* const Xs = Ws + 2 * 32 * WLD;                                   // [4][16*WLD]
+    float* const Ps = reinterpret_cast<float*>(Xs + 4 * 16 * WLD);          // bias | gamma | beta  [3][N]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int tok0 = (int)blockIdx.x * 64 + wave * 16;
+    const int last_tok = (int)p.M - 1;
+    const int nks = p.K / KSL;
+    const int nchunks = nks * NT_RES;
+    __bf16* const xs = Xs + wave * 16 * WLD;
+
+    u32x4 wreg[WLOADS];
+    const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+    auto load_chunk = [&](int ks, int nt) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / PIECES, piece = f % PIECES;
+            if ((32 * PIECES) % 256 == 0 || row < 32)
+                wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / PIECES, piece = f % PIECES;
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
+        }
+    };
+
+    load_chunk(0, 0);
+    for (int i = tid; i < N; i += 256) {
+        Ps[i] = p.bias ? p.bias[i] : 0.f;
+        Ps[N + i] = p.ln_g ? p.ln_g[i] : 1.f;
+        Ps[2 * N + i] = p.ln_g ? p.ln_b[i] : 0.f;
+    }
+    store_chunk(0);
+
+    const int tok = tok0 + c;
+    const bool valid = tok <= last_tok;
+    const int tokc = valid ? tok : last_tok;           // clamped lanes recompute the last row bit for bit
+    const long yrow = p.y_row_group ? (long)tokc + tokc / p.y_row_group + 1 : (long)tokc;
+    float* const yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy + 4 * q;
+    const float* const resp = p.res ? p.res + (long)(tokc % (int)p.res_rows) * p.ldres + 4 * q : nullptr;
+    constexpr bool PRED = PRE >= PRE_ACC;
+
+    f32x4 acc[NF];
+    bf16x8 xf[KS32];
+    f32x4 pre[NF];
+
+    int chunk = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        stage_x<KSL, WLD, XB, 16>(p, xs, tok0, last_tok, ks * KSL, lane);
+        if constexpr (PRE != PRE_NONE) {
+            if (ks == nks - 1) {
+#pragma unroll
+                for (int t = 0; t < NF; ++t) {
+                    if constexpr (PRE == PRE_RES) pre[t] = *reinterpret_cast<const f32x4*>(resp + 16 * t);
+                    if constexpr (PRE == PRE_ACC) pre[t] = *reinterpret_cast<const f32x4*>(yb + 16 * t);
+                    if constexpr (PRE == PRE_ANY) {
+                        pre[t] = resp ? *reinterpret_cast<const f32x4*>(resp + 16 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.accumulate) pre[t] += *reinterpret_cast<const f32x4*>(yb + 16 * t);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(&xs[c * WLD + 32 * s + 8 * q]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();     // chunk `chunk` is in Ws[chunk & 1] (and Ps on the first pass)
+
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt) {
+            const int buf = nt & 1;      // compile-time after unrolling (NT_RES is even)
+            if (chunk + 1 < nchunks) load_chunk(nt + 1 == NT_RES ? ks + 1 : ks, (nt + 1) % NT_RES);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                if (ks == 0) acc[2 * nt + ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const __bf16* wsb = Ws + buf * 32 * WLD + (16 * ft + c) * WLD + 8 * q;
+#pragma unroll
+                for (int s4 = 0; s4 < KS32 / 4; ++s4) {
+                    bf16x8 wf[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 32 * (4 * s4 + u));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[2 * nt + ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[4 * s4 + u], acc[2 * nt + ft], 0, 0, 0);
+                }
+                if constexpr (KS32 % 4 != 0) {
+#pragma unroll
+                    for (int s = KS32 / 4 * 4; s < KS32; ++s) {
+                        const bf16x8 wf1 = *reinterpret_cast<const bf16x8*>(wsb + 32 * s);
+                        acc[2 * nt + ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf[s], acc[2 * nt + ft], 0, 0, 0);
+                    }
+                }
+            }
+            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+            ++chunk;
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    float sum = 0.f;
+    auto epilogue = [&](auto drop_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value;
+        const float ksd = DROP ? 1.f / (1.f - p.drop.p) : 1.f;
+        const uint64_t dbase = (uint64_t)tokc * p.drop_ld + 4 * q;
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[16 * t + 4 * q]);
+            f32x4 v = acc[t] + bb;
+            if constexpr (DROP) {
+                float f[4];
+                drop_factor4(p.drop, dbase + 16 * t, ksd, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= f[j];
+            }
+            if constexpr (PRE != PRE_NONE) v += pre[t];
+            if (!PRED || valid) *reinterpret_cast<f32x4*>(yb + 16 * t) = v;
+            acc[t] = v;
+            sum += (v[0] + v[1]) + (v[2] + v[3]);
+            if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // bounds the hoisting of LDS reads (registers)
+        }
+    };
+    if (p.drop.p > 0.f) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+
+    if (p.ln_g) {
+        const float invn = 1.f / (float)N;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * invn;
+        float var = 0.f;
+#pragma unroll
+        for (int t = 0; t < NF; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = acc[t][j] - mean;
+                var += d * d;
+            }
+        var += __shfl_xor(var, 16, 64);
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * invn + LN_EPS);
+        float* const lb = p.ln_y + (long)tokc * p.ldy + 4 * q;
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const f32x4 gg_ = *reinterpret_cast<const f32x4*>(&Ps[N + 16 * t + 4 * q]);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[2 * N + 16 * t + 4 * q]);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (acc[t][j] - mean) * rstd * gg_[j] + bb[j];
+            if (!PRED || valid) *reinterpret_cast<f32x4*>(lb + 16 * t) = y;
+            if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q == 0 && valid) {
             p.ln_stats[2 * (long)tok] = mean;
             p.ln_stats[2 * (long)tok + 1] = rstd;
         }
@@ -326,38 +511,46 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
+    // bf16 outputs use the permuted feature order (16 consecutive features per lane -> 16-byte stores); fp32 outputs
+    // keep the MFMA order, where the two lanes of a token write adjacent 16-byte pieces (32 B runs per instruction)
+    constexpr bool PERM = YB;
+    const int arow = PERM ? a_row_of_lane(c) : c;
+    const int hoff = PERM ? 16 * h : 4 * h;      // feature offset of this lane half, group g adds GS * g
+    constexpr int GS = PERM ? 4 : 8;
     const int tok0 = (int)blockIdx.x * 128 + wave * 32;
     const int last_tok = (int)p.M - 1;
     const int ntiles = p.N / 32;
     __bf16* const xs = Xs + wave * 32 * XLDW;
 
-    u32x4 wreg[WLOADS];
+    // two-deep register ring for the weight chunks (see the resident kernel); chunk nt uses set / buffer nt & 1
+    u32x4 wreg[2][WLOADS];
     const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
-    auto load_chunk = [&](int nt) {
+    auto load_chunk = [&](int set, int nt) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + 8 * piece);
+            if ((32 * PIECES) % 256 == 0 || row < 32) wreg[set][i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + 8 * piece);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int set) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[set * 32 * WLD + row * WLD + 8 * piece]) = wreg[set][i];
         }
     };
 
-    load_chunk(0);
+    load_chunk(0, 0);
+    if (ntiles > 1) load_chunk(1, 1);
     for (int i = tid; i < p.N; i += 256) Ps[i] = p.bias ? p.bias[i] : 0.f;
     store_chunk(0);
 
     bf16x8 xf[KSL / 16];
 #pragma unroll
     for (int q = 0; q < KSL / XW; ++q) {
-        stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
+        if (!(p.dbg & 8)) stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -371,78 +564,104 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     const bool valid = tok <= last_tok;
     const int tokc = valid ? tok : last_tok;          // clamped lanes recompute the last row bit for bit (see above)
     const long yrow = p.y_row_group ? (long)tokc + tokc / p.y_row_group + 1 : (long)tokc;
-    const long ybase = yrow * p.ldy + 4 * h;
-    const long mbase = (long)tokc * p.ldref + 4 * h;
+    const long ybase = yrow * p.ldy + hoff;
+    const long mbase = (long)tokc * p.ldref + hoff;
     const uint64_t dbase = (uint64_t)tokc * p.drop_ld;
     const float floor_ = p.act_relu ? 0.f : -__builtin_inff();
-    const bool drop_on = EPI == EPI_DROP || (EPI == EPI_ANY && p.drop.p > 0.f);
+    const bool drop_on = (EPI == EPI_DROP || (EPI == EPI_ANY && p.drop.p > 0.f)) && !(p.dbg & 32);
     const bool mask_on = EPI == EPI_MASK || (EPI == EPI_ANY && p.mask_ref != nullptr);
     const bool acc_on = EPI == EPI_ANY && !YB && p.accumulate;
     const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
     constexpr bool PRED = EPI == EPI_ANY;
 
-    for (int nt = 0; nt < ntiles; ++nt) {
-        const int buf = nt & 1;
-        const bool more = nt + 1 < ntiles;
-        if (more) load_chunk(nt + 1);
+    auto tile = [&](auto buf_tag, int nt) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (nt + 2 < ntiles && !(p.dbg & 4)) load_chunk(buf, nt + 2);
         // operands of this tile's epilogue are requested before the MFMA chain
         f32x4 mm[4], yy[4];
         if (mask_on) {
+            if (p.mask_bf16) {     // only the sign matters: expand the bf16 values to fp32 bit patterns
+                if constexpr (PERM) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (p.mask_bf16) {     // only the sign matters: expand the four bf16 to fp32 bit patterns
-                    const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.mask_ref) + mbase + nt * 32 + 8 * g);
-                    mm[g] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
-                                  __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.mask_ref) + mbase + nt * 32 + 8 * g2);
+                        mm[2 * g2] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                                           __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                        mm[2 * g2 + 1] = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+                                               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+                    }
                 } else {
-                    mm[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask_ref) + mbase + nt * 32 + 8 * g);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.mask_ref) + mbase + nt * 32 + 8 * g);
+                        mm[g] = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                                      __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mm[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask_ref) + mbase + nt * 32 + GS * g);
             }
         }
         if (acc_on) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) yy[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + 8 * g);
+            for (int g = 0; g < 4; ++g) yy[g] = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + GS * g);
         }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const __bf16* wsb = Ws + buf * 32 * WLD + c * WLD + 8 * h;
+        const __bf16* wsb = Ws + buf * 32 * WLD + arow * WLD + 8 * h;
 #pragma unroll
         for (int s4 = 0; s4 < KSL / 64; ++s4) {
             bf16x8 wf[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
+            if (!(p.dbg & 2)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
+            }
         }
+        unsigned packed[8];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = nt * 32 + 8 * g + 4 * h;
+            const int n = nt * 32 + hoff + GS * g;
             const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[n]);
             f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
             v += bb;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_);
             if (drop_on) {
+                float f[4];
+                drop_factor4(p.drop, dbase + n, ksd, f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= drop_factor(p.drop, dbase + n + j, ksd);
+                for (int j = 0; j < 4; ++j) v[j] *= f[j];
             }
             if (mask_on) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = mm[g][j] > 0.f ? v[j] * p.mask_scale : 0.f;
             }
             if (acc_on) v += yy[g];
-            if (!PRED || valid) {
-                if constexpr (YB) {
-                    u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(p.Y) + ybase + nt * 32 + 8 * g) = w;
-                } else {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + 8 * g) = v;
-                }
+            if constexpr (YB) {
+                packed[2 * g] = pack2(v[0], v[1]);
+                packed[2 * g + 1] = pack2(v[2], v[3]);
+            } else {
+                if ((!PRED || valid) && !((p.dbg & 1) && v[0] != 1234.5f))
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + GS * g) = v;
             }
         }
-        if (more) store_chunk(buf ^ 1);
+        if constexpr (YB) {     // 16 consecutive features of this lane's row: two 16-byte stores
+            if ((!PRED || valid) && !((p.dbg & 1) && packed[0] != 0x12345u)) {
+                __bf16* yp = reinterpret_cast<__bf16*>(p.Y) + ybase + nt * 32;
+                *reinterpret_cast<u32x4*>(yp) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+                *reinterpret_cast<u32x4*>(yp + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
+            }
+        }
+        if (nt + 1 < ntiles) store_chunk(buf ^ 1);
         __syncthreads();
+    };
+    for (int nt = 0; nt < ntiles; nt += 2) {
+        tile(std::integral_constant<int, 0>{}, nt);
+        if (nt + 1 < ntiles) tile(std::integral_constant<int, 1>{}, nt + 1);
     }
 }
 
@@ -469,6 +688,19 @@ int launch_res(const TlinP& p, hipStream_t st) {
     }
     const long blocks = (p.M + 127) / 128;
     hipLaunchKernelGGL((tlin_res_kernel<NT_RES, KSL, XB, PRE>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int NT_RES, int KSL, bool XB, int PRE>
+int launch_res16(const TlinP& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)(2 * 32 + 4 * 16) * (KSL + 8) * 2 + (size_t)3 * 32 * NT_RES * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_res16_kernel<NT_RES, KSL, XB, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const long blocks = (p.M + 63) / 64;
+    hipLaunchKernelGGL((tlin_res16_kernel<NT_RES, KSL, XB, PRE>), dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -504,6 +736,13 @@ int launch_res_t(const TlinP& p, hipStream_t st) {
     return p.x_bf16 ? launch_res<NT_RES, KSL, true, PRE>(p, st) : launch_res<NT_RES, KSL, false, PRE>(p, st);
 }
 int launch_res_256(const TlinP& p, hipStream_t st) {
+    static const bool v32 = getenv("GG_TLIN_RES32") != nullptr;
+    if (p.x_bf16 && !v32) {
+        if (p.res && p.accumulate) return launch_res16<8, 256, true, PRE_ANY>(p, st);
+        if (p.res) return launch_res16<8, 256, true, PRE_RES>(p, st);
+        if (p.accumulate) return launch_res16<8, 256, true, PRE_ACC>(p, st);
+        return launch_res16<8, 256, true, PRE_NONE>(p, st);
+    }
     if (p.res && p.accumulate) return launch_res_t<8, 256, PRE_ANY>(p, st);
     if (p.res) return launch_res_t<8, 256, PRE_RES>(p, st);
     if (p.accumulate) return launch_res_t<8, 256, PRE_ACC>(p, st);
@@ -525,6 +764,7 @@ bool tlin_supported(const TlinP& p) {
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
     if (p.y_bf16 && p.accumulate) return false;
+    if (p.drop.p > 0.f && p.drop_ld % 2) return false;      // the epilogues hash element PAIRS (drop_rng.h)
     if (!needs_resident(p)) return (size_t)p.N * 4 <= 64 * 1024;     // bias vector in LDS
     if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue
     if (p.N == 256) return p.K % 256 == 0;
@@ -533,8 +773,11 @@ bool tlin_supported(const TlinP& p) {
     return false;
 }
 
-int tlin(const TlinP& p, hipStream_t st) {
-    GG_REQUIRE(tlin_supported(p), "tlin: unsupported shape / alignment");
+int tlin(const TlinP& p_in, hipStream_t st) {
+    GG_REQUIRE(tlin_supported(p_in), "tlin: unsupported shape / alignment");
+    static const int dbg = getenv("GG_TLIN_DBG") ? atoi(getenv("GG_TLIN_DBG")) : 0;
+    TlinP p = p_in;
+    p.dbg = dbg;
     if (!needs_resident(p)) {
         if (p.K == 256) return launch_str_256(p, st);
         if (p.K == 128) return launch_str_t<128, EPI_ANY>(p, st);

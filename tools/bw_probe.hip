@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void mix_probe(const unsigned short* X, const 
 __global__ void copy_probe(const f4* a, f4* b, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
 }
+
+// (h) bf16 output, lane owns a row and writes 8-byte pieces (stream-kernel epilogue, 32x32 MFMA layout): 32 rows x 2 x 8 B
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+__global__ void wr_lane_rows_bf16(unsigned short* Y, long M, int N) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    long r = w * 32 + c; if (r >= M) return;
+    for (int nt = 0; nt < N / 32; ++nt) for (int g = 0; g < 4; ++g) { u2 v = {(unsigned)nt, 2u}; *(u2*)(Y + r * N + nt * 32 + 8 * g + 4 * h) = v; }
+}
+// (i) same bytes, each instruction writes 16 rows x 64 contiguous bytes (4 lanes x 16 B per row)
+__global__ void wr_rows64_bf16(unsigned short* Y, long M, int N) {
+    const int lane = threadIdx.x & 63; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    for (int nt = 0; nt < N / 32; ++nt) for (int i = 0; i < 2; ++i) { long r = w * 32 + i * 16 + (lane >> 2); if (r < M) { u4 v = {(unsigned)nt, 2u, 3u, 4u}; *(u4*)(Y + r * N + nt * 32 + 8 * (lane & 3)) = v; } }
+}
+// (j) same bytes, 32 B per lane (16 features): 32 rows x 2 x 32 B via two 16-B stores
+__global__ void wr_lane32_bf16(unsigned short* Y, long M, int N) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5; const long w = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    long r = w * 32 + c; if (r >= M) return;
+    for (int nt = 0; nt < N / 32; ++nt) for (int g = 0; g < 2; ++g) { u4 v = {(unsigned)nt, 2u, 3u, 4u}; *(u4*)(Y + r * N + nt * 32 + 16 * h + 8 * g) = v; }
+}
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize(); hipEventRecord(a); for (int i = 0; i < 10; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
@@ -101,6 +120,15 @@ int main() {
         const long n = M * 256;   // 16-B elements: 808 MB each way
         float t = timeit([&] { copy_probe<<<256 * 8, 256>>>((const f4*)X, (f4*)Y, n); });
         printf("copy 2x%.0f MB: %7.1f us %6.2f TB/s (read+write)\n", n * 16.0 / 1e6, t, 2.0 * n * 16 / t / 1e6);
+    }
+    for (int N : {512, 768}) {
+        const long wv = (M + 31) / 32; const int bl = (int)((wv + 3) / 4);
+        float t = timeit([&] { wr_lane_rows_bf16<<<bl, 256>>>((unsigned short*)Y, M, N); });
+        printf("write bf16 lane-row 8B   N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 2.0 / t / 1e6);
+        t = timeit([&] { wr_rows64_bf16<<<bl, 256>>>((unsigned short*)Y, M, N); });
+        printf("write bf16 16rows x 64B  N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 2.0 / t / 1e6);
+        t = timeit([&] { wr_lane32_bf16<<<bl, 256>>>((unsigned short*)Y, M, N); });
+        printf("write bf16 lane 2x16B    N=%4d: %7.1f us %6.2f TB/s\n", N, t, M * N * 2.0 / t / 1e6);
     }
     return 0;
 }
