@@ -76,8 +76,9 @@ struct CondActs {
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     uint8_t* mask;
     LayerActs L[MAXL];
-    float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar;
-    bool sqx = false;
+    float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar, *t2i_qt;
+    bool sqx = false;          // projection-free single-query T2I attention, generic kernel
+    bool sqx2 = false;         // ... streaming kernels with the per-head projections hoisted into batched GEMMs
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
 };
@@ -133,7 +134,7 @@ struct gg_engine {
     int wgrad_on = 1;          // dedicated long-reduction weight-gradient kernel (bf16 mode)
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
-    float *s_dqt;
+    float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
     float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
@@ -234,6 +235,7 @@ void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
     c.t2i_ctx = a.take<float>(RB * E);
     c.t2i_out = a.take<float>(RB * E);
     c.t2i_xbar = a.take<float>(RB * nh * E);
+    c.t2i_qt = a.take<float>(RB * nh * E);
     c.i2t_q = a.take<float>(RB * E);
     c.i2t_kv = a.take<float>(RB * T * 2 * E);
     c.i2t_P = a.take<float>(RB * nh * T);
@@ -291,6 +293,7 @@ size_t carve(gg_engine* e, void* base) {
     e->s_dgb = a.take<float>(B * 2 * Dp);
     e->s_delta = a.take<float>(Rb * nh * S);
     e->s_dqt = a.take<float>(Rb * nh * E);
+    e->s_dxbar = a.take<float>(Rb * nh * E);
     return a.off + 256;
 }
 
@@ -591,8 +594,26 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     }
     // T2I: query = text CLS embedding, keys = values = encoder output (R:218)
     GG_TRY(lin_fwd(c, tok, (long)T * E, w + n.t2i.inw, E, w + n.t2i.inb, a.t2i_q, E, (int)RB, E, E));
-    a.sqx = e->sqx_on && sqx_supported(S, E, nh);
-    if (a.sqx) {
+    a.sqx2 = e->sqx_on && sqx_stream_supported(S, E, nh);
+    a.sqx = !a.sqx2 && e->sqx_on && sqx_supported(S, E, nh);
+    if (a.sqx2) {
+        // K / V projections folded into the query side (sqattn.hip): qt_h = Wk_h^T q_h as a per-head batched GEMM,
+        // ONE sweep over the encoder output (scores, online softmax, xbar_h = sum_s p x_s), ctx_h = Wv_h xbar_h + bv
+        GemmP p;
+        p.M = (int)RB; p.N = E; p.K = dh; p.batch = nh; p.batch_inner = 1;
+        p.A = a.t2i_q; p.lda = E; p.layA = LAY_KC; p.sAo = dh;
+        p.B = w + n.t2i.inw + (long)E * E; p.ldb = E; p.layB = LAY_KS; p.sBo = (long)dh * E;
+        p.C = a.t2i_qt; p.ldc = (long)nh * E; p.sCo = E;
+        GG_TRY(run_gemm(c, p));
+        KL(sqx_stream_fwd(a.t2i_qt, x_in, a.mask, B, a.t2i_P, a.t2i_xbar, (int)RB, S, E, nh, c.st));
+        KL(k_copy_rows_bcast(a.t2i_ctx, w + n.t2i.inb + 2 * E, RB, 1, E, c.st));
+        GemmP v;
+        v.M = (int)RB; v.N = dh; v.K = E; v.batch = nh; v.batch_inner = 1; v.accumulate = 1;
+        v.A = a.t2i_xbar; v.lda = (long)nh * E; v.layA = LAY_KC; v.sAo = E;
+        v.B = w + n.t2i.inw + 2L * E * E; v.ldb = E; v.layB = LAY_KC; v.sBo = (long)dh * E;
+        v.C = a.t2i_ctx; v.ldc = E; v.sCo = dh;
+        GG_TRY(run_gemm(c, v));
+    } else if (a.sqx) {
         // K / V projections folded into the query side: one fused per-sample kernel streams the encoder output
         KL(sqx_attn_fwd(a.t2i_q, x_in, w + n.t2i.inw, w + n.t2i.inb, a.mask, B, a.t2i_P, a.t2i_xbar, a.t2i_ctx, (int)RB, S, E, nh, c.st));
     } else {
@@ -648,8 +669,25 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     GG_TRY(lin_bwd_weight(c, e->s_dp, E, a.t2i_ctx, E, g + n.t2i.ow, E, (int)RB, E, E));
     KL(k_colsum(e->s_dp, RB, E, E, g + n.t2i.ob, c.st));
     GG_TRY(lin_bwd_data(c, e->s_dp, E, w + n.t2i.ow, E, e->s_tmpE, E, (int)RB, E, E));
-    if (a.sqx) {
-        KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq, e->s_dqt, (int)RB, S, E, nh, c.st));
+    if (a.sqx || a.sqx2) {
+        if (a.sqx2) {
+            // dxbar_h = Wv_h^T dctx_h ; one sweep over the encoder output (dx written, dqt accumulated) ; dq_h = Wk_h dqt_h
+            GemmP p;
+            p.M = (int)RB; p.N = E; p.K = dh; p.batch = nh; p.batch_inner = 1;
+            p.A = e->s_tmpE; p.lda = E; p.layA = LAY_KC; p.sAo = dh;
+            p.B = w + n.t2i.inw + 2L * E * E; p.ldb = E; p.layB = LAY_KS; p.sBo = (long)dh * E;
+            p.C = e->s_dxbar; p.ldc = (long)nh * E; p.sCo = E;
+            GG_TRY(run_gemm(c, p));
+            KL(sqx_stream_bwd(e->s_dxbar, a.t2i_qt, a.t2i_xbar, enc, a.t2i_P, e->sdx, e->s_dqt, (int)RB, S, E, nh, c.st));
+            GemmP v;
+            v.M = (int)RB; v.N = dh; v.K = E; v.batch = nh; v.batch_inner = 1;
+            v.A = e->s_dqt; v.lda = (long)nh * E; v.layA = LAY_KC; v.sAo = E;
+            v.B = w + n.t2i.inw + (long)E * E; v.ldb = E; v.layB = LAY_KC; v.sBo = (long)dh * E;
+            v.C = e->s_dq; v.ldc = E; v.sCo = dh;
+            GG_TRY(run_gemm(c, v));
+        } else {
+            KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq, e->s_dqt, (int)RB, S, E, nh, c.st));
+        }
         {   // dWk_h += q_h (x) dqt_h  and  dWv_h += dctx_h (x) xbar_h, summed over the batch (per-head small GEMMs)
             GemmP p;
             p.M = dh; p.N = E; p.K = (int)RB; p.layA = LAY_KS; p.layB = LAY_KS; p.lda = E; p.ldb = (long)nh * E; p.ldc = E;

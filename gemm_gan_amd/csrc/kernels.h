@@ -125,6 +125,7 @@ struct TlinP {
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
     int dbg = 0;                                    // timing experiments only (GG_TLIN_DBG): 1 no stores, 2 no MFMA, 4 no weight loads, 8 no X loads
+    unsigned long long* stamps = nullptr;           // tools/tlin_probe: 4 s_memtime stamps per workgroup (wave 0)
 };
 bool tlin_supported(const TlinP& p);
 int tlin(const TlinP& p, hipStream_t st);
@@ -140,6 +141,15 @@ int sqx_attn_fwd(const float* q, const float* x, const float* Win, const float* 
 // dctx [N,E] -> dx [N,S,E], dq [N,E], dqt [N,nh,E]  (dWk_h += q_h (x) dqt_h and dWv_h += dctx_h (x) xbar_h are the caller's GEMMs)
 int sqx_attn_bwd(const float* dctx, const float* q, const float* x, const float* Win, const float* probs, float* dx, float* dq,
                  float* dqt, int N, int S, int E, int nh, hipStream_t st);
+
+// streaming variant: the per-head projections are the caller's batched GEMMs; x is read once per pass
+//   forward : qt [N,nh,E] (= Wk_h^T q_h) -> probs [N,nh,S], xbar [N,nh,E]
+//   backward: dxbar [N,nh,E] (= Wv_h^T dctx_h), qt, xbar, probs -> dx [N,S,E] (overwritten), dqt [N,nh,E]
+bool sqx_stream_supported(int S, int E, int nh);
+int sqx_stream_fwd(const float* qt, const float* x, const uint8_t* mask, int mask_B, float* probs, float* xbar, int N, int S, int E,
+                   int nh, hipStream_t st);
+int sqx_stream_bwd(const float* dxbar, const float* qt, const float* xbar, const float* x, const float* probs, float* dx, float* dqt,
+                   int N, int S, int E, int nh, hipStream_t st);
 
 // weight gradient dW[N,K] += dY[M,N]^T X[M,K] over long token reductions (wgrad.hip), operands fp32 or bf16 --------
 bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, long M, int N, int K);

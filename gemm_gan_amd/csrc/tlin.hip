@@ -542,6 +542,8 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
         }
     };
 
+    unsigned long long t_start = 0, t_x = 0, t_it0 = 0;
+    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
     load_chunk(0, 0);
     if (ntiles > 1) load_chunk(1, 1);
     for (int i = tid; i < p.N; i += 256) Ps[i] = p.bias ? p.bias[i] : 0.f;
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    if (p.stamps) t_x = __builtin_amdgcn_s_memtime();
 
     const int tok = tok0 + c;
     const bool valid = tok <= last_tok;
@@ -662,6 +665,11 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     for (int nt = 0; nt < ntiles; nt += 2) {
         tile(std::integral_constant<int, 0>{}, nt);
         if (nt + 1 < ntiles) tile(std::integral_constant<int, 1>{}, nt + 1);
+        if (p.stamps && nt == 0) t_it0 = __builtin_amdgcn_s_memtime();
+    }
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + 4 * (long)blockIdx.x;
+        o[0] = t_start; o[1] = t_x; o[2] = t_it0; o[3] = __builtin_amdgcn_s_memtime();
     }
 }
 
