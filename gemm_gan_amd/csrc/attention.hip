@@ -178,6 +178,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     stage_transposed<DH, IOB>(Vt, qkv, base + 2 * E, ld, S, Sp, tid, 256);
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
+    uint8_t* Mt = Ms + Sp;                                 // per key tile: does it hold any masked / padded key?
+    for (int t = tid; t < Sp / 32; t += 256) {
+        uint8_t any = 0;
+        for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
+        Mt[t] = any;
+    }
+    __syncthreads();
 
     const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
@@ -206,11 +213,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
                 s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
             }
             float mt = -INFINITY;
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kt * 32 + acc_row(i, h);
-                s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
-                mt = fmaxf(mt, s16[i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            } else {                    // tile without masked keys: no per-element mask lookups
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s16[i] *= sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mn = fmaxf(m, mt);
@@ -316,6 +331,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
     stage_transposed<DH, IOB>(Kt, qkv, base + E, ld, S, Sp, tid, 256);
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
+    uint8_t* Mt = Ms + Sp;                                 // per key tile: does it hold any masked / padded key?
+    for (int t = tid; t < Sp / 32; t += 256) {
+        uint8_t any = 0;
+        for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
+        Mt[t] = any;
+    }
+    __syncthreads();
 
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
@@ -369,11 +391,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
                     dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
                 }
             }
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kt * 32 + acc_row(i, h);
-                const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
-                s16[i] = p * (dp16[i] - dl) * scale;
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
+                    s16[i] = p * (dp16[i] - dl) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(s16[i] * sc - L2) * (dp16[i] - dl) * scale;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
     constexpr int KS = DH / 16;
     __shared__ __attribute__((aligned(16))) __bf16 Qr[4][32 * LDR];
     __shared__ __attribute__((aligned(16))) __bf16 Dr[4][32 * LDR];
-    __shared__ float Ls[4][32], Dl[4][32];
+    __shared__ __attribute__((aligned(16))) float Ls[4][32], Dl[4][32];
 
     const int Sp = (S + 31) / 32 * 32;
     const int nqt = Sp / 32, nkt = Sp / 32;
@@ -470,6 +497,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
 
     __bf16* qimg = Qr[wave];
     __bf16* dimg = Dr[wave];
+    // dropout stream constants of this lane (drop_rng.h): pair state of (row 0 of tile 0, this key), row step, parity
+    const int par = c & 1;
+    const uint32_t Sd = (uint32_t)drop_attn_ld(S);
+    const uint32_t rowmul = (Sd / 2) * DROP_PHI;
+    const uint32_t stile = drop_state(drop, (((uint64_t)nhid * S) * Sd) / 2 + (uint64_t)(key >> 1)) + (uint32_t)(par + 4 * h) * rowmul;
+    const int shl = par ? 0 : 16;                      // odd element -> high half, even element -> low half
+    const uint32_t thr_hi = drop.thr << 16;
     for (int qt = 0; qt < nqt; ++qt) {
         const int q = qt * 32 + c;
         bf16x8 qa[KS], da[KS];
@@ -496,20 +530,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
             s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s], kf[s], s16, 0, 0, 0);
             dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[s], vf[s], dp16, 0, 0, 0);
         }
+        // rows 8g + 4h .. +3 of the tile (registers 4g .. 4g+3): log-sum-exp and delta as two 16-byte LDS reads per group
+        f32x4 lsv[4], dlv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            lsv[g] = *reinterpret_cast<const f32x4*>(&Ls[wave][8 * g + 4 * h]);
+            dlv[g] = *reinterpret_cast<const f32x4*>(&Dl[wave][8 * g + 4 * h]);
+        }
+        // Dropout: element (row qq, key) pairs with key ^ 1, i.e. with the NEIGHBOUR LANE.  Each lane hashes the rows of
+        // its own parity (8 of its 16 registers) and fetches the other 8 hashes from its partner with one DPP move:
+        // half a hash per element.  state(row) is linear in the row (drop_rng.h).
+        uint32_t bits[16];
+        if (drop.p > 0.f) {
+            const uint32_t st = stile + (uint32_t)(qt * 32) * rowmul;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t mine = drop_bits(st + (uint32_t)(2 * (k & 1) + 8 * (k >> 1)) * rowmul);      // row of register 2k + par
+                const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                bits[2 * k] = par ? theirs : mine;
+                bits[2 * k + 1] = par ? mine : theirs;
+            }
+        }
+        const bool rows_full = qt * 32 + 32 <= S;
         f32x16 pd16;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = acc_row(i, h);
-            const int qq = qt * 32 + row;
-            float pd = 0.f, ds = 0.f;
-            if (kvalid && qq < S) {
-                const float p = fast_exp2(s16[i] * sc - Ls[wave][row]);
-                const float kfac = drop.p > 0.f ? drop_factor(drop, ((uint64_t)nhid * S + (uint64_t)qq) * (uint64_t)drop_attn_ld(S) + (uint64_t)key, ks) : 1.f;
-                pd = p * kfac;
-                ds = p * (dp16[i] * kfac - Dl[wave][row]) * scale;
+            const float p = fast_exp2(s16[i] * sc - lsv[i >> 2][i & 3]);
+            float pk = p, dpk = dp16[i];
+            if (drop.p > 0.f) {
+                const bool keep = (bits[i] << shl) >= thr_hi;
+                pk = keep ? p * ks : 0.f;
+                dpk = keep ? dpk * ks : 0.f;
             }
-            pd16[i] = pd;
-            s16[i] = ds;
+            float ds = p * (dpk - dlv[i >> 2][i & 3]) * scale;
+            const bool ok = kvalid && (rows_full || qt * 32 + acc_row(i, h) < S);
+            pd16[i] = ok ? pk : 0.f;
+            s16[i] = ok ? ds : 0.f;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -545,11 +601,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
 
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 16;
+    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16;
 }
 size_t dq_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 16;
+    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16;
 }
 
 template <typename K>

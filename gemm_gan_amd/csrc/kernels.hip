@@ -172,15 +172,28 @@ int k_write_cls(float* seq, const float* cls, int B, int S, int E, hipStream_t s
     write_cls_k<<<nblocks((long)B * E), TPB, 0, st>>>(seq, cls, B, S, E);
     GG_LAUNCH_CHECK();
 }
+// dcls[e] += sum_b dseq[b, 0, e]: the B rows are S*E floats apart, so the batch is split over blockIdx.y and every
+// thread keeps 8 loads in flight; partial sums meet in dcls through atomics (contiguous 256 B per wave)
 __global__ void cls_grad_k(const float* dseq, float* dcls, int B, int S, int E) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dseq[(long)b * S * E + e];
-    dcls[e] += s;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = dseq[(long)(b + u) * S * E + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; b < b1; ++b) s += dseq[(long)b * S * E + e];
+    atomicAdd(dcls + e, s);
 }
 int k_cls_grad(const float* dseq, float* dcls, int B, int S, int E, hipStream_t st) {
-    cls_grad_k<<<(E + 63) / 64, 64, 0, st>>>(dseq, dcls, B, S, E);
+    dim3 grid((E + 63) / 64, B >= 64 ? 16 : 1);
+    cls_grad_k<<<grid, 64, 0, st>>>(dseq, dcls, B, S, E);
     GG_LAUNCH_CHECK();
 }
 __global__ void build_mask_k(const uint8_t* pad, uint8_t* out, int B, int P) {

@@ -577,8 +577,14 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
     constexpr bool PRED = EPI == EPI_ANY;
 
-    auto tile = [&](auto buf_tag, int nt) {
-        constexpr int buf = decltype(buf_tag)::value;
+    // bf16 results are held back for CB = 4 feature chunks and written together: per token 4 x 64 contiguous bytes in
+    // one burst (full 128-byte lines reach L2 / HBM at once).  Written chunk by chunk, a row's 64-byte pieces arrive
+    // microseconds apart and the write stream measured 3.5 TB/s against 5.7 for the burst shape (tools/bw_probe).
+    constexpr int CB = 4;
+    unsigned held[CB][8];
+    auto tile = [&](auto slot_tag, int nt) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int buf = slot & 1;
         if (nt + 2 < ntiles && !(p.dbg & 4)) load_chunk(buf, nt + 2);
         // operands of this tile's epilogue are requested before the MFMA chain
         f32x4 mm[4], yy[4];
@@ -624,7 +630,6 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
                 for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
             }
         }
-        unsigned packed[8];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nt * 32 + hoff + GS * g;
@@ -645,27 +650,39 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
             }
             if (acc_on) v += yy[g];
             if constexpr (YB) {
-                packed[2 * g] = pack2(v[0], v[1]);
-                packed[2 * g + 1] = pack2(v[2], v[3]);
+                held[slot][2 * g] = pack2(v[0], v[1]);
+                held[slot][2 * g + 1] = pack2(v[2], v[3]);
             } else {
                 if ((!PRED || valid) && !((p.dbg & 1) && v[0] != 1234.5f))
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + GS * g) = v;
             }
         }
-        if constexpr (YB) {     // 16 consecutive features of this lane's row: two 16-byte stores
-            if ((!PRED || valid) && !((p.dbg & 1) && packed[0] != 0x12345u)) {
-                __bf16* yp = reinterpret_cast<__bf16*>(p.Y) + ybase + nt * 32;
-                *reinterpret_cast<u32x4*>(yp) = u32x4{packed[0], packed[1], packed[2], packed[3]};
-                *reinterpret_cast<u32x4*>(yp + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
+        if constexpr (YB) {     // 16 consecutive features of this lane's row per chunk: two 16-byte stores each
+            if (slot == CB - 1 || nt + 1 == ntiles) {
+                if ((!PRED || valid) && !((p.dbg & 1) && held[0][0] != 0x12345u)) {
+                    __bf16* yp = reinterpret_cast<__bf16*>(p.Y) + ybase + (nt - slot) * 32;
+#pragma unroll
+                    for (int q = 0; q <= slot; ++q) {
+                        if constexpr (PERM) {
+                            *reinterpret_cast<u32x4*>(yp + 32 * q) = u32x4{held[q][0], held[q][1], held[q][2], held[q][3]};
+                            *reinterpret_cast<u32x4*>(yp + 32 * q + 8) = u32x4{held[q][4], held[q][5], held[q][6], held[q][7]};
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(yp + 32 * q + GS * g) = u32x2{held[q][2 * g], held[q][2 * g + 1]};
+                        }
+                    }
+                }
             }
         }
         if (nt + 1 < ntiles) store_chunk(buf ^ 1);
         __syncthreads();
     };
-    for (int nt = 0; nt < ntiles; nt += 2) {
+    for (int nt = 0; nt < ntiles; nt += CB) {
         tile(std::integral_constant<int, 0>{}, nt);
         if (nt + 1 < ntiles) tile(std::integral_constant<int, 1>{}, nt + 1);
         if (p.stamps && nt == 0) t_it0 = __builtin_amdgcn_s_memtime();
+        if (nt + 2 < ntiles) tile(std::integral_constant<int, 2>{}, nt + 2);
+        if (nt + 3 < ntiles) tile(std::integral_constant<int, 3>{}, nt + 3);
     }
     if (p.stamps && tid == 0) {
         unsigned long long* o = p.stamps + 4 * (long)blockIdx.x;

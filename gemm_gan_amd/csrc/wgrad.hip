@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const int panels_k = (K + PK - 1) / PK;
-    const int panel = blockIdx.x / splits, split = blockIdx.x % splits;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own L2.  All panels of
+    // one token split read the SAME rows of dY / X, so they are made neighbours on one XCD (consecutive b / 8) and
+    // the second .. last panel of a split hit that XCD's L2 instead of fetching the rows again.
+    const int npanels = panels_k * ((N + PN - 1) / PN);
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    const int split = (j / npanels) * 8 + xcd, panel = j % npanels;
+    if (split >= splits) return;
     const int n0 = (panel / panels_k) * PN, k0 = (panel % panels_k) * PK;
     const int nvalid = min(PN, N - n0), kvalid = min(PK, K - k0);
     // token range of this split, in whole chunks
@@ -120,37 +126,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    Stager<YB, PN> sy;
-    Stager<XB, PK> sx;
-    sy.load(dY, ldy, c_beg * CT, M, n0, nvalid, tid, true);
-    sx.load(X, ldx, c_beg * CT, M, k0, kvalid, tid, false);
-    sy.store(Ysb(0), LDY, tid);
-    sx.store(Xsb(0), LDX, tid);
-    __syncthreads();
-    for (long ch = c_beg; ch < c_end; ++ch) {
-        const int buf = (int)((ch - c_beg) & 1);
-        const bool more = ch + 1 < c_end;
-        if (more) {
-            sy.load(dY, ldy, (ch + 1) * CT, M, n0, nvalid, tid, true);
-            sx.load(X, ldx, (ch + 1) * CT, M, k0, kvalid, tid, false);
+    // Token chunks travel HBM -> registers -> LDS through a ring of DEPTH register stages: chunk r + DEPTH is
+    // requested when chunk r is multiplied and written to LDS DEPTH - 1 chunks later, so an HBM round trip is
+    // covered by DEPTH - 1 MFMA passes (one pass = 32 MFMAs, far shorter than the memory latency on its own).
+    constexpr int DEPTH = 4;
+    Stager<YB, PN> sy[DEPTH];
+    Stager<XB, PK> sx[DEPTH];
+    const long nch = c_end - c_beg;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if (d < nch) {
+            sy[d].load(dY, ldy, (c_beg + d) * CT, M, n0, nvalid, tid, true);
+            sx[d].load(X, ldx, (c_beg + d) * CT, M, k0, kvalid, tid, false);
         }
+    }
+    sy[0].store(Ysb(0), LDY, tid);
+    sx[0].store(Xsb(0), LDX, tid);
+    __syncthreads();
+    for (long r0 = 0; r0 < nch; r0 += DEPTH) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 af[WT];
+        for (int u = 0; u < DEPTH; ++u) {
+            const long r = r0 + u;
+            if (r < nch) {
+                const int buf = (int)(r & 1);
+                if (r + DEPTH < nch) {
+                    sy[u].load(dY, ldy, (c_beg + r + DEPTH) * CT, M, n0, nvalid, tid, true);
+                    sx[u].load(X, ldx, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid, false);
+                }
 #pragma unroll
-            for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 af[WT];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bf16x8 bf = frag_tr(Xsb(buf), LDX, b * 32, s2, lane);
+                    for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
 #pragma unroll
-                for (int a = 0; a < WT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < 8; ++b) {
+                        const bf16x8 bf = frag_tr(Xsb(buf), LDX, b * 32, s2, lane);
+#pragma unroll
+                        for (int a = 0; a < WT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+                    }
+                }
+                if (r + 1 < nch) {
+                    sy[(u + 1) % DEPTH].store(Ysb(buf ^ 1), LDY, tid);
+                    sx[(u + 1) % DEPTH].store(Xsb(buf ^ 1), LDX, tid);
+                }
+                __syncthreads();
             }
         }
-        if (more) {
-            sy.store(Ysb(buf ^ 1), LDY, tid);
-            sx.store(Xsb(buf ^ 1), LDX, tid);
-        }
-        __syncthreads();
     }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
     float* wbase = dW + (long)(n0 + wave * (32 * WT) + 4 * h) * ldw + k0 + c;
@@ -186,7 +207,9 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     // one workgroup per CU (256 accumulator registers => one wave per SIMD): panels x splits ~ 256; every extra
     // split costs a 256 KB atomic panel add, every missing one idles a CU
     int splits = (int)std::max<long>(1, std::min<long>(chunks / 8, (256 + panels - 1) / panels));
-    const dim3 grid((unsigned)(panels * splits));
+    if (splits >= 8) splits = splits / 8 * 8;            // whole groups of 8 splits (one per XCD), never more than 256 workgroups
+    const int split_groups = (splits + 7) / 8;
+    const dim3 grid((unsigned)(panels * split_groups * 8));
     constexpr int SMEM = 2 * CT * (LDY + LDX) * 2;
 #define GG_WG(YB, XB)                                                                                                  \
     do {                                                                                                               \
