@@ -228,9 +228,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
                 }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float mn = fmaxf(m, mt);
-            const float mref = (mn == -INFINITY) ? 0.f : mn;
-            const float alpha = fast_exp2(m - mref);
+            // Lazy reference update: the softmax reference m only moves when a tile's maximum exceeds it by more than
+            // 2^8 (scores are in the log2 domain), so p <= 256 in between - exact after the final O / l - and the
+            // O *= alpha pass over the 32 output accumulators is skipped for almost every tile.
+            const bool move = mt > m + 8.f;
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const float mn = move ? mt : m;
+                const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);      // mn is finite wherever move is set
+                l *= alpha;
+                m = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            }
+            const float mref = (m == -INFINITY) ? 0.f : m;
             float lt = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -239,12 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
                 s16[i] = p;
             }
             lt += __shfl_xor(lt, 32, 64);
-            l = l * alpha + lt;
-            m = mn;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            l += lt;
             if (drop.p > 0.f) {     // registers 4g..4g+3 hold 4 consecutive keys: two pair hashes
                 const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
 #pragma unroll
