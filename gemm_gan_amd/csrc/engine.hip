@@ -445,7 +445,8 @@ int try_tlin(Ctx& c, const TlinP& p) {
         // algorithmic bytes at the element sizes actually stored: X once, Y once (+ LayerNorm output), residual,
         // previous Y when accumulating, sign-mask reference, bf16 weights once
         const double MN = (double)p.M * p.N;
-        r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MN + (p.ln_g ? 4.0 * MN : 0.0) +
+        const double MNy = (p.y_rows >= 0 && p.y_rows < p.M) ? (double)p.y_rows * p.N : MN;     // rows whose pre-LN sum is stored
+        r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MNy + (p.ln_g ? 4.0 * MN : 0.0) +
                   (p.res ? 4.0 * MN : 0.0) + (p.accumulate ? 4.0 * MN : 0.0) + (p.mask_ref ? (p.mask_bf16 ? 2.0 : 4.0) * MN : 0.0) +
                   2.0 * p.N * p.K;
         r.e0 = e->prof_pool[e->prof_next++];
@@ -479,11 +480,13 @@ DropKey dkey(gg_engine* e, const CondActs& a, int net, int layer, int site) {
 // ------------------------------------------------------------------------------------------------
 // conditioning stack forward (R:198-224)   [numpy_oracle.cond_fwd]
 // ------------------------------------------------------------------------------------------------
-int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float drop) {
+// keep: number of leading replicas whose backward will run (their pre-LayerNorm sums are stored); -1 = all
+int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float drop, int keep = -1) {
     gg_engine* e = c.e;
     const int B = in->B, P = in->P, T = in->T, S = P + 1, E = e->E, F = e->F, nh = e->nh, dh = e->dh;
     const int Dt = e->Dt, Dp = e->Dp;
     const long RB = (long)R * B;
+    const long keep_rows = keep < 0 ? -1 : (long)keep * B * S;
     a.B = B; a.R = R; a.P = P; a.T = T; a.drop = drop; a.call = ++e->call_counter;
     const float* w = n.w;
     // FiLM parameters from the text CLS token (row b of `text` viewed with ld = T*Dt)
@@ -559,7 +562,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             TlinP t;
             t.X = L.ctx; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.ow); t.ldw = E; t.bias = w + lp.sa.ob;
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
-            t.res = x_in; t.ldres = E; t.res_rows = RB * S;
+            t.res = x_in; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
@@ -582,7 +585,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             TlinP t;
             t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
             t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
-            t.res = L.x1; t.ldres = E; t.res_rows = RB * S;
+            t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
@@ -893,11 +896,11 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
     return 0;
 }
 
-int generator_forward(Ctx& c, const float* z, const gg_cond* in, float* x_out, int train) {
+int generator_forward(Ctx& c, const float* z, const gg_cond* in, float* x_out, int train, int keep = -1) {
     gg_engine* e = c.e;
     Net& n = e->net[GG_ROLE_GENERATOR];
     const int B = in->B;
-    GG_TRY(cond_forward(c, n, in, e->actsG, 1, train ? e->dropout : 0.f));
+    GG_TRY(cond_forward(c, n, in, e->actsG, 1, train ? e->dropout : 0.f, keep));
     GG_TRY(lin_fwd(c, z, e->L, n.w + n.w1, e->L + e->E, nullptr, e->headG.a1, e->H, B, e->H, e->L));
     GG_TRY(head_finish(c, n, e->actsG.c, e->headG.a1, e->headG.a2, x_out, e->G, B, B));
     return 0;
@@ -937,10 +940,10 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
     KL(k_fill(D.g, D.total, 0.f, c.st));
     // x_fake = G(z) (generator frozen: no activations kept beyond this call)   R:391
-    GG_TRY(generator_forward(c, z, in, e->X2, 1));
+    GG_TRY(generator_forward(c, z, in, e->X2, 1, 0));
     KL(k_copy(e->X2 + (long)B * G, x_real, (long)B * G, c.st));
     // critic conditioning: R independent dropout replicas (fake, real, interpolate) R:403,404,360
-    GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout));
+    GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
     if (R == 1) KL(k_copy_rows_bcast(e->c3, e->actsD.c, 3L * B, B, E, c.st));
     else KL(k_copy(e->c3, e->actsD.c, 3L * B * E, c.st));
     // first layer, gene part, for fake and real rows at once; the interpolate's is their lerp
@@ -992,7 +995,7 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
     KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
     KL(k_fill(Gn.g, Gn.total, 0.f, c.st));
     GG_TRY(generator_forward(c, z, in, e->X2, 1));                       // R:441 (activations kept in actsG/headG)
-    GG_TRY(cond_forward(c, D, in, e->actsD, 1, e->dropout));             // R:449
+    GG_TRY(cond_forward(c, D, in, e->actsD, 1, e->dropout, 0));          // R:449 (frozen critic: forward only)
     GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->headD.a1, H, B, H, G));
     GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, e->headD.out, 1, B, B));
     KL(k_gen_loss_seed(e->headD.out, e->dseed, losses, B, c.st));

@@ -115,6 +115,8 @@ struct TlinP {
     const void* W = nullptr; long ldw = 0;          // bf16 [N][K] (row stride ldw elements)
     const float* bias = nullptr;
     void* Y = nullptr; long ldy = 0; int y_bf16 = 0;                          // output fp32 or (stream mode only) bf16
+    long y_rows = -1;                               // resident + LayerNorm: Y (pre-LN sum) is stored for tokens < y_rows only (-1: all);
+                                                    // forward-only replicas never read it back
     int N = 0, K = 0;
     const float* film_g = nullptr; const float* film_b = nullptr; long film_ld = 0; int film_group = 0;   // X' = g*X + b
     int y_row_group = 0;                            // output row m -> m + m / group + 1

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
     float* const yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy;
     const float* const resp = p.res ? p.res + (long)(tokc % (int)p.res_rows) * p.ldres : nullptr;
     constexpr bool PRED = PRE >= PRE_ACC;
+    const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
 
     f32x16 acc[NT_RES];
     bf16x8 xf[KSL / 16];
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
                 if constexpr (PRE != PRE_NONE) v += pre[nt][g];
-                if ((!PRED || valid) && !((p.dbg & 1) && v[0] != 1234.5f)) *reinterpret_cast<f32x4*>(yb + n) = v;
+                if ((!PRED || valid) && keep_y && !((p.dbg & 1) && v[0] != 1234.5f)) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[nt][4 * g + j] = v[j];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (h == 0 && valid) {
+        if (h == 0 && valid && keep_y) {
             p.ln_stats[2 * (long)tok] = mean;
             p.ln_stats[2 * (long)tok + 1] = rstd;
         }
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
     float* const yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy + 4 * q;
     const float* const resp = p.res ? p.res + (long)(tokc % (int)p.res_rows) * p.ldres + 4 * q : nullptr;
     constexpr bool PRED = PRE >= PRE_ACC;
+    const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
 
     f32x4 acc[NF];
     bf16x8 xf[KS32];
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
                 for (int j = 0; j < 4; ++j) v[j] *= f[j];
             }
             if constexpr (PRE != PRE_NONE) v += pre[t];
-            if (!PRED || valid) *reinterpret_cast<f32x4*>(yb + 16 * t) = v;
+            if ((!PRED || valid) && keep_y) *reinterpret_cast<f32x4*>(yb + 16 * t) = v;
             acc[t] = v;
             sum += (v[0] + v[1]) + (v[2] + v[3]);
             if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // bounds the hoisting of LDS reads (registers)
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
             if (!PRED || valid) *reinterpret_cast<f32x4*>(lb + 16 * t) = y;
             if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        if (q == 0 && valid) {
+        if (q == 0 && valid && keep_y) {
             p.ln_stats[2 * (long)tok] = mean;
             p.ln_stats[2 * (long)tok + 1] = rstd;
         }
