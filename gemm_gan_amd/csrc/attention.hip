@@ -45,6 +45,10 @@ __device__ __forceinline__ bf16x8 frag_from_acc(const f32x16& a, int s2) {   // 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 constexpr float LOG2E = 1.4426950408889634f;
+// Query tiles are dealt to the 4 waves of a workgroup round-robin.  When one tile is left over (S = 257: eight full
+// tiles + the CLS row) and it holds at most CO_MAXQ queries, all four waves share it - each takes every 4th key tile -
+// and merge their partial results through LDS, instead of one wave walking a third pass alone (27 -> 21 tile steps).
+constexpr int CO_MAXQ = 2;       // 3 partial sets (waves 1..3) x CO_MAXQ x (DH + 2) floats must fit beside K / V^T below 80 KB (two workgroups per CU)
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 // 8 consecutive elements at element offset `off` of a fp32 (IOB = false) or bf16 (IOB = true) tensor, as an MFMA fragment
 template <bool IOB>
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
     uint8_t* Mt = Ms + Sp;                                 // per key tile: does it hold any masked / padded key?
+    float* Co = reinterpret_cast<float*>(Mt + 64);        // [waves 1..3][CO_MAXQ][DH + 2] partials of the shared query tile
     for (int t = tid; t < Sp / 32; t += 256) {
         uint8_t any = 0;
         for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
@@ -189,7 +194,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     const int nqt = Sp / 32, nkt = Sp / 32;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    const bool coop = (nqt % 4 == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;      // workgroup-uniform
+    const int nq_main = coop ? nqt - 1 : nqt;
+    for (int it = wave; it < nq_main + (coop ? 4 : 0); it += 4) {
+        const bool shared = it >= nq_main;             // the left-over tile: every wave passes here exactly once
+        const int qt = shared ? nqt - 1 : it;
+        const int kt0 = shared ? wave : 0, kstep = shared ? 4 : 1;
         const int q = qt * 32 + c;
         bf16x8 qf[KS];
         const int qc = min(q, S - 1);                  // rows past the end re-read the last query: never stored
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
             for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
         // dropout stream state of this lane's row at its first key pair (drop_rng.h: linear in the pair index)
         const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
-        for (int kt = 0; kt < nkt; ++kt) {
+        for (int kt = kt0; kt < nkt; kt += kstep) {
             f32x16 s16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s16[i] = 0.f;
@@ -273,6 +283,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
                 }
             }
         }
+        if (shared) {      // merge the four key-range partials of the shared tile (softmax-weighted) in wave 0
+            if (wave != 0 && q < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
+                if (h == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) part[2 + d] = O[dt][i];
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (q < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (DH + 2);
+                constexpr int WS = CO_MAXQ * (DH + 2);
+                const float M = fmaxf(fmaxf(m, p0[0]), fmaxf(p0[WS], p0[2 * WS]));
+                const float mref = (M == -INFINITY) ? 0.f : M;
+                const float w0 = fast_exp2(m - mref);
+                float wg[3];
+                l *= w0;
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    wg[w] = fast_exp2(p0[w * WS] - mref);
+                    l += p0[w * WS + 1] * wg[w];
+                }
+                m = M;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = min(dt * 32 + acc_row(i, h), DH - 1);
+                        float v = O[dt][i] * w0;
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) v += p0[w * WS + 2 + d] * wg[w];
+                        O[dt][i] = v;
+                    }
+            }
+        }
         if (q < S) {
             const float inv = ks / l;
             const long out = ((long)n * S + q) * E + hd * DH;
@@ -339,6 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
     __syncthreads();
     uint8_t* Mt = Ms + Sp;                                 // per key tile: does it hold any masked / padded key?
+    float* Co = reinterpret_cast<float*>(Mt + 64);        // [waves 1..3][CO_MAXQ][DH + 2] partials of the shared query tile
     for (int t = tid; t < Sp / 32; t += 256) {
         uint8_t any = 0;
         for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
@@ -350,7 +401,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
     const float sc = scale * LOG2E;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     const int nqt = Sp / 32, nkt = Sp / 32;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    const bool coop = (nqt % 4 == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;      // see CO_MAXQ
+    const int nq_main = coop ? nqt - 1 : nqt;
+    for (int it = wave; it < nq_main + (coop ? 4 : 0); it += 4) {
+        const bool shared = it >= nq_main;
+        const int qt = shared ? nqt - 1 : it;
+        const int kt0 = shared ? wave : 0, kstep = shared ? 4 : 1;
         const int q = qt * 32 + c;
         bf16x8 qf[KS], df[KS];
         float L2 = 0.f, dl = 0.f;
@@ -369,14 +425,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
         }
         // delta[q] = sum_d dO*O : this lane-half covered half of the head dim, the other half the rest
         dl += __shfl_xor(dl, 32, 64);
-        if (q < S && h == 0) delta[(long)blockIdx.x * S + q] = dl;      // consumed by the dK/dV kernel
+        if (q < S && h == 0 && (!shared || wave == 0)) delta[(long)blockIdx.x * S + q] = dl;      // consumed by the dK/dV kernel
         f32x16 dQ[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
         const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
-        for (int kt = 0; kt < nkt; ++kt) {
+        for (int kt = kt0; kt < nkt; kt += kstep) {
             f32x16 s16, dp16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
@@ -417,6 +473,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
                     const bf16x8 kf = frag_transposed(Kt, LDT, min(dt * 32 + c, DH - 1), kt * 32, s2, h);
                     dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[dt], 0, 0, 0);
                 }
+            }
+        }
+        if (shared) {      // sum the four key-range partials of the shared tile in wave 0
+            if (wave != 0 && q < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) part[d] = dQ[dt][i];
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (q < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (DH + 2);
+                constexpr int WS = CO_MAXQ * (DH + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = min(dt * 32 + acc_row(i, h), DH - 1);
+                        dQ[dt][i] += p0[d] + p0[WS + d] + p0[2 * WS + d];
+                    }
             }
         }
         if (q < S) {
@@ -608,11 +689,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
 
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16;
+    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 size_t dq_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16;
+    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 
 template <typename K>

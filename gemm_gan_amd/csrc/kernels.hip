@@ -58,10 +58,22 @@ int k_fill(float* x, long n, float v, hipStream_t st) {
     fill_k<<<nblocks(n, TPB, 4096), TPB, 0, st>>>(x, n, v);
     GG_LAUNCH_CHECK();
 }
+// device-to-device copy as a plain kernel: a launch is several microseconds cheaper on the host than hipMemcpyAsync
+__global__ void copy_k(float* dst, const float* src, long n, int vec) {
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = i0; i < n4; i += step) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+        for (long i = (n4 << 2) + i0; i < n; i += step) dst[i] = src[i];
+    } else {
+        for (long i = i0; i < n; i += step) dst[i] = src[i];
+    }
+}
 int k_copy(float* dst, const float* src, long n, hipStream_t st) {
     if (n <= 0) return 0;
-    GG_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    copy_k<<<nblocks(vec ? (n + 3) / 4 : n, TPB, 8192), TPB, 0, st>>>(dst, src, n, vec);
+    GG_LAUNCH_CHECK();
 }
 __global__ void copy_rows_bcast_k(float* dst, const float* src, long rows, long src_rows, int cols) {
     const long n = rows * cols;

@@ -19,6 +19,9 @@ CASES = {
                                            text_dims=512, patch_dims=1024, dropout=0.0), B=8, P=64, T=1),
     "leaky_T300": dict(cfg=PathConfig(n_genes=130, latent_dims=32, embedding_dims=32, hidden_dims=64, text_dims=24,
                                        patch_dims=16, dropout=0.0, negative_slope=0.2), B=6, P=9, T=300),
+    # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
+    "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
+                                          patch_dims=64, dropout=0.0), B=3, P=256, T=1),
 }
 
 
@@ -181,7 +184,7 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_flash_attention_matches_unfused_path(case, dropout):
     """Fused attention forward/backward (attention.hip) against the unfused bf16 path (GEMM + softmax +
