@@ -75,9 +75,9 @@ def pmc_traffic(cls):
     except Exception:
         return None
     if "resident" in cls:
-        pref = ("tlin_kernel<32, 8", "tlin_kernel<32, 4", "tlin_kernel<32, 2")
+        pref = ("tlin_res16_kernel", "tlin_res_kernel")
     elif "stream" in cls:
-        pref = ("tlin_kernel<32, 0",)
+        pref = ("tlin_str_kernel",)
     else:
         pref = (cls.split("<")[0],)
     n = b = 0.0
