@@ -73,27 +73,27 @@ __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, in
         const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
         constexpr int GB = NLD < 8 ? NLD : 8;     // loads in flight per batch (register budget)
         if (p.film_g) {
-            constexpr int GF = GB < 4 ? GB : 4;
-            // FiLM group of a row: 32 consecutive rows cross at most one group boundary (film_group >= 32)
+            // FiLM rows are per SAMPLE (film_group tokens): 32 consecutive tokens touch at most two of them
+            // (film_group >= 32), so gamma / beta of both groups are fetched once per call for this lane's columns and
+            // the activation rows keep the same batched loads as the plain path.
             const int tb = min(tok0, last_tok);
             const int g0 = tb / p.film_group, rem0 = tb - g0 * p.film_group;
-            const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g);
-            const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b);
+            const int g1 = min(g0 + 1, last_tok / p.film_group);
             const unsigned fldb = (unsigned)p.film_ld * 4u;
+            const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g) + cb;
+            const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b) + cb;
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g0 * fldb), ba = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g0 * fldb);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g1 * fldb), bb = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g1 * fldb);
 #pragma unroll
-            for (int b0 = 0; b0 < NLD; b0 += GF) {
-                f32x4 v[GF], g[GF], b[GF];
+            for (int b0 = 0; b0 < NLD; b0 += GB) {
+                f32x4 v[GB];
 #pragma unroll
-                for (int i = 0; i < GF; ++i) {
+                for (int i = 0; i < GB; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + i), last_tok) * ldb + cb));
+#pragma unroll
+                for (int i = 0; i < GB; ++i) {
                     const int r = min(tok0 + lrow + RPI * (b0 + i), last_tok);
-                    v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)r * ldb + cb));
-                    const unsigned fo = (unsigned)(g0 + (rem0 + (r - tb) >= p.film_group ? 1 : 0)) * fldb + cb;
-                    g[i] = *reinterpret_cast<const f32x4*>(Gc + fo);
-                    b[i] = *reinterpret_cast<const f32x4*>(Bc + fo);
-                }
-#pragma unroll
-                for (int i = 0; i < GF; ++i) {
-                    const f32x4 m = g[i] * v[i] + b[i];
+                    const bool second = rem0 + (r - tb) >= p.film_group;
+                    const f32x4 m = (second ? gb : ga) * v[i] + (second ? bb : ba);
                     u32x2 w = {pack2(m[0], m[1]), pack2(m[2], m[3])};
                     *reinterpret_cast<u32x2*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = w;
                 }
