@@ -372,8 +372,13 @@ int lin_bwd_data(Ctx& c, const float* dY, long ldy, const float* W, long ldw, fl
 }
 
 // dW[N,K] += dY[M,N]^T @ X[M,K]     (reduction over the M rows, split over workgroups, fp32 atomics)
+// film: X is used as  g[m / group] * X + b[m / group]  (the FiLM-modulated patches) without materialising it; only the
+// token-reduction kernel implements it - callers check wgrad_film_ok() first
+bool wgrad_film_ok(gg_engine* e, const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, int group) {
+    return e->wgrad_on && e->precision == GG_PREC_BF16 && group >= 32 && wgrad_supported(dY, ldy, 0, X, ldx, 0, M, N, K);
+}
 int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                   int dy_bf16 = 0, int x_bf16 = 0) {
+                   int dy_bf16 = 0, int x_bf16 = 0, const WgradFilm* film = nullptr) {
     gg_engine* e = c.e;
     if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
         e->launches++;
@@ -393,13 +398,14 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
             r.e1 = e->prof_pool[e->prof_next++];
             GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
         }
-        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st));
+        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film));
         if (e->prof_on) {
             GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
             e->prof_recs.push_back(r);
         }
         return 0;
     }
+    GG_REQUIRE(!film, "lin_bwd_weight: FiLM operand needs the token-reduction kernel");
     GemmP p;
     p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
     p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = dy_bf16; p.b_bf16 = x_bf16;
@@ -828,8 +834,15 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     }
     KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
     KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
-    KL(k_film_mod(in->patches, a.gb, e->s_mod, B, P, Dp, c.st));
-    GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
+    if (wgrad_film_ok(e, e->s_demb, E, in->patches, Dp, B * P, E, Dp, P)) {
+        // dW_pe += demb^T (gamma * patches + beta): the modulation is applied while the token chunks are staged
+        WgradFilm f;
+        f.g = a.gb; f.b = a.gb + Dp; f.ld = 2 * Dp; f.group = P;
+        GG_TRY(lin_bwd_weight(c, e->s_demb, E, in->patches, Dp, g + n.pe_w, Dp, B * P, E, Dp, 0, 0, &f));
+    } else {
+        KL(k_film_mod(in->patches, a.gb, e->s_mod, B, P, Dp, c.st));
+        GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
+    }
     KL(k_colsum(e->s_demb, (long)B * P, E, E, g + n.pe_b, c.st));
     {
         TlinP t;

@@ -155,8 +155,10 @@ int sqx_stream_bwd(const float* dxbar, const float* qt, const float* xbar, const
 
 // weight gradient dW[N,K] += dY[M,N]^T X[M,K] over long token reductions (wgrad.hip), operands fp32 or bf16 --------
 bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, long M, int N, int K);
+// optional FiLM on the X operand: X' = g[token / group] * X + b[token / group]  (rows of g / b are ld floats apart)
+struct WgradFilm { const float* g = nullptr; const float* b = nullptr; long ld = 0; int group = 0; };
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st);
+          hipStream_t st, const WgradFilm* film = nullptr);
 
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);

@@ -50,6 +50,8 @@ struct Stager {
     static constexpr int PPR = W / (BF ? 8 : 4);             // 16-byte pieces per row
     static constexpr int NP = CT * PPR / 256;                // pieces per thread
     u32x4 r[NP];
+    f32x4 fga, fba, fgb, fbb;      // FiLM (fp32 X only): gamma / beta of the two samples a 32-token chunk can touch, this thread's columns
+    int fsplit;                    // first row of the chunk that belongs to the second sample
     // Unconditional loads (rows / columns past the end are clamped to valid addresses so nothing branches and all
     // pieces are in flight together); `zero` blanks the out-of-range pieces afterwards - needed for dY only: a zero
     // dY row/column contributes nothing whatever X holds, and out-of-range X columns only feed unstored outputs.
@@ -76,6 +78,29 @@ struct Stager {
             }
         }
     }
+    // X' = gamma[sample] * X + beta[sample], sample = token / group: requested together with the chunk's rows
+    __device__ __forceinline__ void load_film(const float* fg, const float* fb, long fld, int group, long tok0, long tok_end, int col0,
+                                              int cols_valid, int tid) {
+        const int pc = tid % PPR;
+        const int cc = min(4 * pc, cols_valid - 4);
+        const long t0 = min(tok0, tok_end - 1);
+        const long g0 = t0 / group, g1 = min(g0 + 1, (tok_end - 1) / group);
+        fsplit = (int)((g0 + 1) * group - tok0);
+        fga = *reinterpret_cast<const f32x4*>(fg + g0 * fld + col0 + cc);
+        fba = *reinterpret_cast<const f32x4*>(fb + g0 * fld + col0 + cc);
+        fgb = *reinterpret_cast<const f32x4*>(fg + g1 * fld + col0 + cc);
+        fbb = *reinterpret_cast<const f32x4*>(fb + g1 * fld + col0 + cc);
+    }
+    __device__ __forceinline__ void store_film(__bf16* img, int ld, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+            const bool second = row >= fsplit;
+            const f32x4 v = (second ? fgb : fga) * __builtin_bit_cast(f32x4, r[i]) + (second ? fbb : fba);
+            u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+        }
+    }
     __device__ __forceinline__ void store(__bf16* img, int ld, int tid) const {
         if constexpr (BF) {
 #pragma unroll
@@ -95,9 +120,9 @@ struct Stager {
     }
 };
 
-template <bool YB, bool XB>
+template <bool YB, bool XB, bool FILM>
 __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
-                                                    float* __restrict__ dW, long ldw, long M, int N, int K, int splits) {
+                                                    float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
     auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
     auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
@@ -138,10 +163,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
         if (d < nch) {
             sy[d].load(dY, ldy, (c_beg + d) * CT, M, n0, nvalid, tid, true);
             sx[d].load(X, ldx, (c_beg + d) * CT, M, k0, kvalid, tid, false);
+            if constexpr (FILM) sx[d].load_film(film.g, film.b, film.ld, film.group, (c_beg + d) * CT, M, k0, kvalid, tid);
         }
     }
     sy[0].store(Ysb(0), LDY, tid);
-    sx[0].store(Xsb(0), LDX, tid);
+    if constexpr (FILM) sx[0].store_film(Xsb(0), LDX, tid);
+    else sx[0].store(Xsb(0), LDX, tid);
     __syncthreads();
     for (long r0 = 0; r0 < nch; r0 += DEPTH) {
 #pragma unroll
@@ -152,6 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 if (r + DEPTH < nch) {
                     sy[u].load(dY, ldy, (c_beg + r + DEPTH) * CT, M, n0, nvalid, tid, true);
                     sx[u].load(X, ldx, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid, false);
+                    if constexpr (FILM) sx[u].load_film(film.g, film.b, film.ld, film.group, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid);
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -167,7 +195,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 }
                 if (r + 1 < nch) {
                     sy[(u + 1) % DEPTH].store(Ysb(buf ^ 1), LDY, tid);
-                    sx[(u + 1) % DEPTH].store(Xsb(buf ^ 1), LDX, tid);
+                    if constexpr (FILM) sx[(u + 1) % DEPTH].store_film(Xsb(buf ^ 1), LDX, tid);
+                    else sx[(u + 1) % DEPTH].store(Xsb(buf ^ 1), LDX, tid);
                 }
                 __syncthreads();
             }
@@ -200,7 +229,11 @@ bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long 
 }
 
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st) {
+          hipStream_t st, const WgradFilm* film_in) {
+    WgradFilm film;
+    if (film_in) film = *film_in;
+    GG_REQUIRE(!film.g || (!x_bf16 && film.group >= CT && film.ld % 4 == 0 && K % 4 == 0 && al16(film.g) && al16(film.b)),
+               "wgrad: FiLM needs fp32 X, 16-byte aligned gamma / beta rows and at least one chunk of tokens per sample");
     GG_REQUIRE(wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K), "wgrad: unsupported shape / alignment");
     const int panels = ((N + PN - 1) / PN) * ((K + PK - 1) / PK);
     const long chunks = (M + CT - 1) / CT;
@@ -211,20 +244,23 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     const int split_groups = (splits + 7) / 8;
     const dim3 grid((unsigned)(panels * split_groups * 8));
     constexpr int SMEM = 2 * CT * (LDY + LDX) * 2;
-#define GG_WG(YB, XB)                                                                                                  \
+#define GG_WG(YB, XB, FL)                                                                                              \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB>),                     \
+            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL>),                 \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film); \
     } while (0)
-    if (dy_bf16 && x_bf16) GG_WG(true, true);
-    else if (dy_bf16) GG_WG(true, false);
-    else if (x_bf16) GG_WG(false, true);
-    else GG_WG(false, false);
+    if (film.g) {
+        if (dy_bf16) GG_WG(true, false, true);
+        else GG_WG(false, false, true);
+    } else if (dy_bf16 && x_bf16) GG_WG(true, true, false);
+    else if (dy_bf16) GG_WG(true, false, false);
+    else if (x_bf16) GG_WG(false, true, false);
+    else GG_WG(false, false, false);
 #undef GG_WG
     GG_CHECK_HIP(hipGetLastError());
     return 0;

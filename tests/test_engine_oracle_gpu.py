@@ -345,6 +345,7 @@ def test_weight_gradient_kernel_matches_split_k_gemm(case):
         out[on] = {k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()}
     ck = Checker(f"wgrad kernel vs split-K GEMM {case}", 2e-3)
     for k in out[True]:
-        if k.endswith("weight") and "transformer" in k:
+        # encoder weights, and the patch encoder whose X operand is FiLM-modulated on the fly by the kernel
+        if k.endswith("weight") and ("transformer" in k or "patches_encoder" in k):
             ck.check(k, out[True][k], out[False][k])
     ck.done()
