@@ -844,13 +844,19 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
     }
     KL(k_colsum(e->s_demb, (long)B * P, E, E, g + n.pe_b, c.st));
-    {
+    if (wgrad_film_ok(e, e->s_demb, E, in->patches, Dp, B * P, E, Dp, P) && P % 32 == 0) {
+        // FiLM gradients without d(modulated input): dgamma_b = sum_e W (demb_b^T patches_b), dbeta_b = sum_e W (sum_p demb_b)
+        KL(k_fill(e->s_dgb, (long)B * 2 * Dp, 0.f, c.st));
+        WgradFilmGrad f;
+        f.W = w + n.pe_w; f.ldw = Dp; f.dgamma = e->s_dgb; f.dbeta = e->s_dgb + Dp; f.ld = 2 * Dp; f.tokens = P;
+        KL(wgrad(e->s_demb, E, 0, in->patches, Dp, 0, nullptr, 0, (long)B * P, E, Dp, c.st, nullptr, &f));
+    } else {
         TlinP t;
         t.X = e->s_demb; t.ldx = E; t.M = (long)B * P; t.W = WTB(n, n.pe_w); t.ldw = E;
         t.Y = e->s_dmod; t.ldy = Dp; t.N = Dp; t.K = E;
         TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_demb, E, w + n.pe_w, Dp, e->s_dmod, Dp, B * P, E, Dp)));
+        KL(k_film_bwd_reduce(e->s_dmod, in->patches, e->s_dgb, B, P, Dp, c.st));
     }
-    KL(k_film_bwd_reduce(e->s_dmod, in->patches, e->s_dgb, B, P, Dp, c.st));
     KL(k_film_act_bwd(e->s_dgb, a.gb, a.gbpre, B, Dp, c.st));
     GG_TRY(lin_bwd_weight(c, e->s_dgb, 2 * Dp, in->text, (long)T * Dt, g + n.film_w, Dt, B, 2 * Dp, Dt));
     KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));

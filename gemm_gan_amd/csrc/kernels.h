@@ -157,8 +157,11 @@ int sqx_stream_bwd(const float* dxbar, const float* qt, const float* xbar, const
 bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, long M, int N, int K);
 // optional FiLM on the X operand: X' = g[token / group] * X + b[token / group]  (rows of g / b are ld floats apart)
 struct WgradFilm { const float* g = nullptr; const float* b = nullptr; long ld = 0; int group = 0; };
+// FiLM-gradient mode: nothing is added to dW; per sample b (`tokens` rows each) the panel C_b = dY_b^T X_b is contracted
+// with W [N,K]:  dgamma[b,k] += sum_n W[n,k] C_b[n,k],  dbeta[b,k] += sum_n W[n,k] sum_tokens dY_b[token,n]
+struct WgradFilmGrad { const float* W = nullptr; long ldw = 0; float* dgamma = nullptr; float* dbeta = nullptr; long ld = 0; int tokens = 0; };
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film = nullptr);
+          hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr);
 
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);

@@ -120,9 +120,14 @@ struct Stager {
     }
 };
 
-template <bool YB, bool XB, bool FILM>
+// FGRAD: instead of dW += panel, the panel C_b = dY_b^T X_b of ONE sample b (split = sample) is contracted with the
+// weight matrix W [N,K] it belongs to:   dgamma[b,k] += sum_n W[n,k] C_b[n,k],   dbeta[b,k] += sum_n W[n,k] s_b[n],
+// s_b[n] = sum_tokens dY_b[token,n]  - the gradients of a FiLM modulation X' = gamma_b * X + beta_b that sits in front of
+// the Linear W, without materialising d(X') = dY W  (dgamma = sum_tokens dX' * X, dbeta = sum_tokens dX').
+template <bool YB, bool XB, bool FILM, bool FGRAD>
 __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
-                                                    float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film) {
+                                                    float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
+                                                    WgradFilmGrad fg) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
     auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
     auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
@@ -140,8 +145,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     const int nvalid = min(PN, N - n0), kvalid = min(PK, K - k0);
     // token range of this split, in whole chunks
     const long chunks = (M + CT - 1) / CT;
-    const long c_beg = chunks * split / splits, c_end = chunks * (split + 1) / splits;
+    long c_beg = chunks * split / splits, c_end = chunks * (split + 1) / splits;
+    if constexpr (FGRAD) {                              // split = sample: its tokens are whole chunks (tokens % CT == 0)
+        c_beg = (long)split * (fg.tokens / CT);
+        c_end = c_beg + fg.tokens / CT;
+    }
     if (c_beg >= c_end) return;
+    float ssum = 0.f;                                   // FGRAD: sum over tokens of dY[token, row 32*wave + c] (this lane's half of every 16)
 
     f32x16 acc[WT][8];
 #pragma unroll
@@ -186,6 +196,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                     bf16x8 af[WT];
 #pragma unroll
                     for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
+                    if constexpr (FGRAD) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)af[0][j] << 16);
+                    }
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         const bf16x8 bf = frag_tr(Xsb(buf), LDX, b * 32, s2, lane);
@@ -201,6 +215,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 __syncthreads();
             }
         }
+    }
+    if constexpr (FGRAD) {
+        // s of the wave's 32 rows -> LDS (the staging buffers are free after the last barrier), then per register row
+        ssum += __shfl_xor(ssum, 32, 64);
+        float* sl = reinterpret_cast<float*>(wg_smem) + wave * 32;
+        if (h == 0) sl[c] = ssum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 sv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(&sl[8 * g + 4 * h]);
+        const float* wb = fg.W + (long)(n0 + wave * 32 + 4 * h) * fg.ldw + k0 + c;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            float vg = 0.f, vb = 0.f;
+            const bool colok = b * 32 + c < kvalid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2);
+                const bool ok = colok && wave * 32 + 4 * h + rr < nvalid;
+                const float w = ok ? wb[(long)rr * fg.ldw + b * 32] : 0.f;
+                vg += acc[0][b][i] * w;
+                vb += sv[i >> 2][i & 3] * w;
+            }
+            vg += __shfl_xor(vg, 32, 64);
+            vb += __shfl_xor(vb, 32, 64);
+            if (h == 0 && colok) {
+                atomicAdd(fg.dgamma + (long)split * fg.ld + k0 + b * 32 + c, vg);
+                atomicAdd(fg.dbeta + (long)split * fg.ld + k0 + b * 32 + c, vb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
     }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
     float* wbase = dW + (long)(n0 + wave * (32 * WT) + 4 * h) * ldw + k0 + c;
@@ -229,9 +276,13 @@ bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long 
 }
 
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film_in) {
+          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in) {
     WgradFilm film;
     if (film_in) film = *film_in;
+    WgradFilmGrad fgrad;
+    if (fgrad_in) fgrad = *fgrad_in;
+    GG_REQUIRE(!fgrad.W || (!film.g && !dy_bf16 && !x_bf16 && fgrad.tokens >= CT && fgrad.tokens % CT == 0 && M % fgrad.tokens == 0),
+               "wgrad: FiLM-gradient mode needs fp32 operands and whole 32-token chunks per sample");
     GG_REQUIRE(!film.g || (!x_bf16 && film.group >= CT && film.ld % 4 == 0 && K % 4 == 0 && al16(film.g) && al16(film.b)),
                "wgrad: FiLM needs fp32 X, 16-byte aligned gamma / beta rows and at least one chunk of tokens per sample");
     GG_REQUIRE(wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K), "wgrad: unsupported shape / alignment");
@@ -241,26 +292,29 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     // split costs a 256 KB atomic panel add, every missing one idles a CU
     int splits = (int)std::max<long>(1, std::min<long>(chunks / 8, (256 + panels - 1) / panels));
     if (splits >= 8) splits = splits / 8 * 8;            // whole groups of 8 splits (one per XCD), never more than 256 workgroups
+    if (fgrad.W) splits = (int)(M / fgrad.tokens);      // one split per sample
     const int split_groups = (splits + 7) / 8;
     const dim3 grid((unsigned)(panels * split_groups * 8));
     constexpr int SMEM = 2 * CT * (LDY + LDX) * 2;
-#define GG_WG(YB, XB, FL)                                                                                              \
+#define GG_WG(YB, XB, FL, FG)                                                                                              \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL>),                 \
+            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL, FG>),             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad); \
     } while (0)
-    if (film.g) {
-        if (dy_bf16) GG_WG(true, false, true);
-        else GG_WG(false, false, true);
-    } else if (dy_bf16 && x_bf16) GG_WG(true, true, false);
-    else if (dy_bf16) GG_WG(true, false, false);
-    else if (x_bf16) GG_WG(false, true, false);
-    else GG_WG(false, false, false);
+    if (fgrad.W) {
+        GG_WG(false, false, false, true);
+    } else if (film.g) {
+        if (dy_bf16) GG_WG(true, false, true, false);
+        else GG_WG(false, false, true, false);
+    } else if (dy_bf16 && x_bf16) GG_WG(true, true, false, false);
+    else if (dy_bf16) GG_WG(true, false, false, false);
+    else if (x_bf16) GG_WG(false, true, false, false);
+    else GG_WG(false, false, false, false);
 #undef GG_WG
     GG_CHECK_HIP(hipGetLastError());
     return 0;

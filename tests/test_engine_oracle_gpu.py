@@ -345,7 +345,12 @@ def test_weight_gradient_kernel_matches_split_k_gemm(case):
         out[on] = {k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()}
     ck = Checker(f"wgrad kernel vs split-K GEMM {case}", 2e-3)
     for k in out[True]:
-        # encoder weights, and the patch encoder whose X operand is FiLM-modulated on the fly by the kernel
+        # encoder weights; the patch encoder, whose X operand is FiLM-modulated on the fly by the kernel; and the FiLM
+        # generator, whose gradient comes from the kernel's per-sample contraction mode (no d(modulated input) tensor)
         if k.endswith("weight") and ("transformer" in k or "patches_encoder" in k):
             ck.check(k, out[True][k], out[False][k])
+        elif "film_generator" in k:
+            # different association: (demb^T patches) . W with bf16 patches, against (demb W) * fp32 patches summed over
+            # tokens - one more operand rounded to bf16, so the bf16 tolerance applies, not the summation-order one
+            ck.check(k, out[True][k], out[False][k], tol=1e-2)
     ck.done()
