@@ -82,6 +82,9 @@ struct CondActs {
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
 };
+// generator outputs that may be computed ahead of the critic iterations that consume them (gg_generator_prefetch)
+constexpr int GG_MAX_PREFETCH = 8;
+
 struct HeadActs {
     float *a1, *a2, *out;   // [rows,H], [rows,H], [rows,OUT]
 };
@@ -118,6 +121,8 @@ struct gg_engine {
     CondActs actsG, actsD;
     HeadActs headG, headD;
     float *X2;                 // [2B, G]: fake rows then real rows
+    float *Xpre = nullptr;     // [GG_MAX_PREFETCH, B, G]: generator outputs of a whole train() computed in batched passes
+    int pre_n = 0, pre_next = 0, pre_B = 0;
     float *c3;                 // [3B, E] conditioning rows for the critic head (fake, real, hat)
     float *Pfr;                // [2B, H] x @ W1x^T for fake / real
     float *dseed;              // [2B]
@@ -133,6 +138,7 @@ struct gg_engine {
     int small_on = 1;          // latency-optimised kernel for few-tile GEMMs (bf16 mode)
     int wgrad_on = 1;          // dedicated long-reduction weight-gradient kernel (bf16 mode)
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
+    int prefetch_on = 1;       // gg_train_step computes the generator outputs of all critic iterations in batched passes
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
@@ -261,6 +267,7 @@ size_t carve(gg_engine* e, void* base) {
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
     e->X2 = a.take<float>(2 * B * G);
+    e->Xpre = a.take<float>((long)GG_MAX_PREFETCH * B * G);
     e->c3 = a.take<float>(3 * B * E);
     e->Pfr = a.take<float>(2 * B * H);
     e->dseed = a.take<float>(2 * B);
@@ -947,7 +954,8 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
     return 0;
 }
 
-int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses) {
+int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses,
+                    const float* x_fake_pre = nullptr) {
     gg_engine* e = c.e;
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H;
@@ -959,7 +967,8 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
     KL(k_fill(D.g, D.total, 0.f, c.st));
     // x_fake = G(z) (generator frozen: no activations kept beyond this call)   R:391
-    GG_TRY(generator_forward(c, z, in, e->X2, 1, 0));
+    if (x_fake_pre) KL(k_copy(e->X2, x_fake_pre, (long)B * G, c.st));      // computed ahead by generator_prefetch
+    else GG_TRY(generator_forward(c, z, in, e->X2, 1, 0));
     KL(k_copy(e->X2 + (long)B * G, x_real, (long)B * G, c.st));
     // critic conditioning: R independent dropout replicas (fake, real, interpolate) R:403,404,360
     GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
@@ -1002,6 +1011,41 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
         GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 2));
     }
     return 0;
+}
+
+// The generator is frozen during the n_critic critic iterations of a train() (R:463-477) and the conditioning batch is
+// the same, so its n forward passes (fresh z, fresh dropout draws) do not depend on the critic updates in between: they
+// run here as dropout replicas stacked on the batch axis - up to maxR at a time, in the critic's activation arena, which
+// is idle before the first critic iteration - instead of n one-replica passes (fewer, larger launches; better tails).
+// Statistically identical to the sequential order: every replica draws its own dropout masks and uses its own z.
+int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
+    gg_engine* e = c.e;
+    Net& Gn = e->net[GG_ROLE_GENERATOR];
+    const int B = in->B, G = e->G, E = e->E, H = e->H, Lz = e->L;
+    e->pre_n = 0; e->pre_next = 0; e->pre_B = B;
+    n = std::min(n, GG_MAX_PREFETCH);
+    if (n < 1) return 0;
+    GG_TRY(refresh_shadows(c, Gn));
+    int done = 0;
+    while (done < n) {
+        const int r = std::min(n - done, e->dropout > 0.f ? e->maxR : 3);      // head scratch (critic's) holds 3B rows
+        const int rc = e->dropout > 0.f ? r : 1;                                // without dropout the conditioning replicas coincide
+        GG_TRY(cond_forward(c, Gn, in, e->actsD, rc, e->dropout, 0));
+        const float* cvec = e->actsD.c;
+        if (rc == 1 && r > 1) {
+            KL(k_copy_rows_bcast(e->c3, e->actsD.c, (long)r * B, B, E, c.st));
+            cvec = e->c3;
+        }
+        GG_TRY(lin_fwd(c, z_all + (long)done * B * Lz, Lz, Gn.w + Gn.w1, Lz + E, nullptr, e->headD.a1, H, r * B, H, Lz));
+        GG_TRY(head_finish(c, Gn, cvec, e->headD.a1, e->headD.a2, e->Xpre + (long)done * B * G, G, r * B, r * B));
+        done += r;
+    }
+    e->pre_n = n;
+    return 0;
+}
+inline const float* next_prefetched(gg_engine* e, int B) {
+    if (e->pre_next >= e->pre_n || e->pre_B != B) return nullptr;
+    return e->Xpre + (long)(e->pre_next++) * B * e->G;
 }
 
 int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
@@ -1125,7 +1169,13 @@ int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const 
     GG_REQUIRE(e && x_real && z && alpha && losses, "null argument");
     GG_TRY(check_cond(e, in));
     Ctx c{e, (hipStream_t)stream};
-    return critic_backward(c, x_real, z, alpha, in, losses);
+    return critic_backward(c, x_real, z, alpha, in, losses, next_prefetched(e, in->B));
+}
+int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond* in, void* stream) {
+    GG_REQUIRE(e && z_all && n >= 0, "bad argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return generator_prefetch(c, z_all, n, in);
 }
 int gg_critic_apply(gg_engine* e, float grad_scale, void* stream) {
     GG_REQUIRE(e, "null argument");
@@ -1141,6 +1191,7 @@ int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* in, float
 int gg_generator_apply(gg_engine* e, float grad_scale, void* stream) {
     GG_REQUIRE(e, "null argument");
     Ctx c{e, (hipStream_t)stream};
+    e->pre_n = e->pre_next = 0;                       // the generator changes: outputs computed ahead are stale
     return apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, grad_scale);
 }
 
@@ -1152,10 +1203,12 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const fl
     Ctx c{e, (hipStream_t)stream};
     e->launches = 0;
     const long zs = (long)in->B * e->L;
+    if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in));
     for (int k = 0; k < n_critic; ++k) {
-        GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses));
+        GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(e, in->B)));
         GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
     }
+    e->pre_n = e->pre_next = 0;
     GG_TRY(generator_backward(c, z_all + n_critic * zs, in, losses));
     GG_TRY(apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, 1.f));
     return 0;
@@ -1175,6 +1228,12 @@ int gg_set_dropout(gg_engine* e, float p) {
 int gg_set_precision(gg_engine* e, int precision) {
     GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16), "bad precision");
     e->precision = precision;
+    return 0;
+}
+int gg_set_prefetch(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->prefetch_on = on != 0;
+    e->pre_n = e->pre_next = 0;
     return 0;
 }
 int gg_set_flash(gg_engine* e, int on) {

@@ -134,6 +134,16 @@ class Engine:
     def generator_apply(self, grad_scale=1.0):
         L.check(self.lib.gg_generator_apply(self.h, C.c_float(grad_scale), _stream()))
 
+    def generator_prefetch(self, z_all, patches, patch_pad, text, text_pad):
+        """Generator outputs for the next len(z_all) critic iterations, computed ahead as stacked replicas (the
+        generator is frozen in between); the following critic_backward calls consume them in order."""
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        assert z_all.dim() == 3 and z_all.is_contiguous()
+        L.check(self.lib.gg_generator_prefetch(self.h, _ptr(z_all), int(z_all.shape[0]), C.byref(cond), _stream()))
+
+    def set_prefetch(self, on):
+        L.check(self.lib.gg_set_prefetch(self.h, int(bool(on))))
+
     def train_step(self, x_real, patches, patch_pad, text, text_pad, z_all, alpha_all):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         n_critic = alpha_all.shape[0]

@@ -337,6 +337,8 @@ class WGAN_GP:
         if w == 1:
             eng.train_step(x, pat, ppad, text, tpad, z_all, alpha_all)     # whole step enqueued by ONE C call
         else:
+            if n > 1:
+                eng.generator_prefetch(z_all[:n].contiguous(), pat, ppad, text, tpad)   # frozen generator: all n passes at once
             for k in range(n):
                 eng.critic_backward(x, z_all[k], alpha_all[k], pat, ppad, text, tpad)
                 self._allreduce(L.ROLE_CRITIC)

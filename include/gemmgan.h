@@ -122,6 +122,16 @@ int gg_critic_apply(gg_engine* e, float grad_scale, void* stream);
 int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* c, float* losses, void* stream);
 int gg_generator_apply(gg_engine* e, float grad_scale, void* stream);
 
+/* ---- optional: the frozen generator's outputs for the next n critic iterations, computed ahead -------------
+ * WGAN_GP.train (R:463-477) calls train_disc n_critic times on ONE conditioning batch with the generator frozen, so
+ * the n generator forward passes (fresh z, fresh dropout draws) do not depend on the critic updates in between.
+ * This call runs them as stacked replicas (z_all [n, B, L]); the following n gg_critic_backward calls with the same
+ * batch size consume the stored outputs in order instead of running the generator (their z argument is then unused).
+ * gg_generator_apply discards what is left.  gg_train_step does this by itself (gg_set_prefetch(e, 0) turns it off);
+ * a data-parallel host loop (all-reduce between *_backward and *_apply) calls it once before its critic loop. */
+int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond* c, void* stream);
+int gg_set_prefetch(gg_engine* e, int on);
+
 /* ---- whole step on one GPU: WGAN_GP.train (R:463-477) -----------------------------------------------
  * z_all [n_critic+1, B, L], alpha_all [n_critic, B]; losses hold the LAST critic iteration's
  * D_real / D_fake / GP (what d_batch_loss reports, R:421) and the generator loss. */

@@ -60,6 +60,9 @@ class OracleEngine:
     def critic_apply(self, scale):
         self._apply(L.ROLE_CRITIC, scale, self.tr.cfg.clip_d, self.tr.opt_d)
 
+    def generator_prefetch(self, z_all, pat, ppad, text, tpad):
+        pass        # a scheduling hint of the HIP engine (batched generator passes): same results without it
+
     def generator_backward(self, z, pat, ppad, text, tpad):
         r = self.tr.generator_iteration(z, (pat, ppad.bool(), text, tpad.bool()), apply=False)
         self._store(L.ROLE_GENERATOR, r["grads"])

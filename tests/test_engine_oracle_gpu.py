@@ -354,3 +354,46 @@ def test_weight_gradient_kernel_matches_split_k_gemm(case):
             # tokens - one more operand rounded to bf16, so the bf16 tolerance applies, not the summation-order one
             ck.check(k, out[True][k], out[False][k], tol=1e-2)
     ck.done()
+
+
+PREC = "f32"
+
+
+def test_generator_prefetch_equals_sequential_passes():
+    """gg_train_step computes the frozen generator's outputs of all critic iterations ahead, as stacked replicas; with
+    dropout 0 (identical arithmetic per row) a step must match the sequential order - through gg_train_step with the
+    switch off, and through the host loop (generator_prefetch + critic_backward/apply) of the data-parallel path."""
+    c = CASES["hot_tiles_E256"]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(7)
+    n = 4
+    z_all = torch.randn(n + 1, B, cfg.latent_dims, generator=g).cuda()
+    alpha_all = torch.rand(n, B, generator=g).cuda()
+    res = {}
+    for mode in ("step_prefetch", "step_sequential", "step_sequential_again", "host_loop"):
+        eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+        load_oracle_state(eng, tr)
+        eng.set_precision(PREC)
+        if mode == "host_loop":
+            eng.generator_prefetch(z_all[:n].contiguous(), patches, patch_pad, text, text_pad)
+            for k in range(n):
+                eng.critic_backward(x, z_all[k].contiguous(), alpha_all[k].contiguous(), patches, patch_pad, text, text_pad)
+                eng.critic_apply(1.0)
+            eng.generator_backward(z_all[n].contiguous(), patches, patch_pad, text, text_pad)
+            eng.generator_apply(1.0)
+        else:
+            eng.set_prefetch(mode == "step_prefetch")
+            eng.train_step(x, patches, patch_pad, text, text_pad, z_all, alpha_all)
+        res[mode] = dict(losses=eng.losses.clone(), wd=eng.flat[L.ROLE_CRITIC]["w"].clone(), wg=eng.flat[L.ROLE_GENERATOR]["w"].clone())
+    ck = Checker(f"generator prefetch vs sequential ({PREC}, dropout 0)", 5e-3)
+    ck.check("run-to-run: losses", res["step_sequential_again"]["losses"], res["step_sequential"]["losses"])
+    ck.check("run-to-run: critic parameters", res["step_sequential_again"]["wd"], res["step_sequential"]["wd"])
+    for other in ("step_sequential", "host_loop"):
+        ck.check(f"losses vs {other}", res["step_prefetch"]["losses"], res[other]["losses"])
+        ck.check(f"critic parameters vs {other}", res["step_prefetch"]["wd"], res[other]["wd"])
+        ck.check(f"generator parameters vs {other}", res["step_prefetch"]["wg"], res[other]["wg"])
+    ck.done()
