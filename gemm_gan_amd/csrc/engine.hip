@@ -384,8 +384,10 @@ int lin_bwd_data(Ctx& c, const float* dY, long ldy, const float* W, long ldw, fl
 bool wgrad_film_ok(gg_engine* e, const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, int group) {
     return e->wgrad_on && e->precision == GG_PREC_BF16 && group >= 32 && wgrad_supported(dY, ldy, 0, X, ldx, 0, M, N, K);
 }
+// dbias: bias gradient (column sums of dY) - folded into the token-reduction kernel when dY is stored in bf16 (the sums
+// then use exactly the stored values), a separate column-sum launch otherwise
 int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                   int dy_bf16 = 0, int x_bf16 = 0, const WgradFilm* film = nullptr) {
+                   int dy_bf16 = 0, int x_bf16 = 0, const WgradFilm* film = nullptr, float* dbias = nullptr) {
     gg_engine* e = c.e;
     if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
         e->launches++;
@@ -405,7 +407,8 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
             r.e1 = e->prof_pool[e->prof_next++];
             GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
         }
-        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film));
+        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr));
+        if (dbias && !dy_bf16) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, 0)); e->launches++; }
         if (e->prof_on) {
             GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
             e->prof_recs.push_back(r);
@@ -413,6 +416,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
         return 0;
     }
     GG_REQUIRE(!film, "lin_bwd_weight: FiLM operand needs the token-reduction kernel");
+    if (dbias) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, dy_bf16)); e->launches++; }
     GemmP p;
     p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
     p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = dy_bf16; p.b_bf16 = x_bf16;
@@ -753,8 +757,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));
             });
         }
-        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0));
-        KL(k_colsum(e->sdh, RB * S, F, F, g + lp.l1b, c.st, bst));
+        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0, nullptr, g + lp.l1b));
         {   // dx1 = dr2 + dhpre W1
             TlinP t;
             t.X = e->sdh; t.ldx = F; t.M = RB * S; t.W = WTB(n, lp.l1w); t.ldw = F;
@@ -820,8 +823,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 GG_TRY(run_gemm(c, p));
             }
         }
-        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0));
-        KL(k_colsum(e->sdqkv, RB * S, 3 * E, 3 * E, g + lp.sa.inb, c.st, bst));
+        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb));
         {   // dx_in = dr1 + dqkv Win
             TlinP t;
             t.X = e->sdqkv; t.ldx = 3 * E; t.M = RB * S; t.W = WTB(n, lp.sa.inw); t.ldw = 3 * E;

@@ -161,7 +161,8 @@ struct WgradFilm { const float* g = nullptr; const float* b = nullptr; long ld =
 // with W [N,K]:  dgamma[b,k] += sum_n W[n,k] C_b[n,k],  dbeta[b,k] += sum_n W[n,k] sum_tokens dY_b[token,n]
 struct WgradFilmGrad { const float* W = nullptr; long ldw = 0; float* dgamma = nullptr; float* dbeta = nullptr; long ld = 0; int tokens = 0; };
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr);
+          hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr, float* dbias = nullptr);
+// dbias (optional): dbias[n] += sum_m dY[m, n] with dY as the kernel sees it (bf16 operand values) - the Linear's bias gradient
 
 // optimiser ---------------------------------------------------------------------------------------
 int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);

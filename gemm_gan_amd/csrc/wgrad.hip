@@ -127,7 +127,7 @@ struct Stager {
 template <bool YB, bool XB, bool FILM, bool FGRAD>
 __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
                                                     float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
-                                                    WgradFilmGrad fg) {
+                                                    WgradFilmGrad fg, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
     auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
     auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
         c_end = c_beg + fg.tokens / CT;
     }
     if (c_beg >= c_end) return;
-    float ssum = 0.f;                                   // FGRAD: sum over tokens of dY[token, row 32*wave + c] (this lane's half of every 16)
+    float ssum = 0.f;                                   // sum over tokens of dY[token, row 32*wave + c] (this lane's half of every 16)
+    const bool do_bias = dbias != nullptr && k0 == 0;   // bias gradient = column sums of dY: once per row panel
 
     f32x16 acc[WT][8];
 #pragma unroll
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                     bf16x8 af[WT];
 #pragma unroll
                     for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
-                    if constexpr (FGRAD) {
+                    if (FGRAD || do_bias) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)af[0][j] << 16);
                     }
@@ -249,6 +250,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
         }
         return;
     }
+    if (do_bias) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        if (h == 0 && wave * 32 + c < nvalid) atomicAdd(dbias + n0 + wave * 32 + c, ssum);
+    }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
     float* wbase = dW + (long)(n0 + wave * (32 * WT) + 4 * h) * ldw + k0 + c;
 #pragma unroll
@@ -276,7 +281,7 @@ bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long 
 }
 
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in) {
+          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in, float* dbias) {
     WgradFilm film;
     if (film_in) film = *film_in;
     WgradFilmGrad fgrad;
@@ -304,7 +309,7 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias); \
     } while (0)
     if (fgrad.W) {
         GG_WG(false, false, false, true);
