@@ -162,7 +162,7 @@ __device__ __forceinline__ bf16x8 frag_transposed(const __bf16* img, int ld, int
 template <int DH, bool IOB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                        int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
-                                                       int S, int E, int nh, DropKey drop) {
+                                                       int S, int E, int nh, DropKey drop, int qkv_B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
-    const long base = (long)n * S * ld + hd * DH;          // element offset of this (sample, head) inside qkv
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;      // this (sample, head) inside qkv; replicas may share one projection
     stage_rows<DH, IOB>(Ks, qkv, base + E, ld, S, Sp, tid, 256);
     stage_transposed<DH, IOB>(Vt, qkv, base + 2 * E, ld, S, Sp, tid, 256);
     for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
                                                           const void* __restrict__ dctx,
                                                           const float* __restrict__ lse2, float* __restrict__ delta,
                                                           const uint8_t* __restrict__ mask, int mask_B,
-                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop) {
+                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
-    const long base = (long)n * S * ld + hd * DH;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
     stage_rows<DH, IOB>(Ks, qkv, base + E, ld, S, Sp, tid, 256);
     stage_rows<DH, IOB>(Vs, qkv, base + 2 * E, ld, S, Sp, tid, 256);
     stage_transposed<DH, IOB>(Kt, qkv, base + E, ld, S, Sp, tid, 256);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
                                                            const float* __restrict__ lse2, const float* __restrict__ delta,
                                                            const uint8_t* __restrict__ mask, int mask_B,
                                                            void* __restrict__ dqkv, int S, int E, int nh, DropKey drop,
-                                                           long total_items) {
+                                                           long total_items, int qkv_B) {
     constexpr int LDR = DH + 8;      // row-major tile [32][DH+8] bf16
     constexpr int DT = (DH + 31) / 32;
     constexpr int KS = DH / 16;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
     const long nhid = item / nkt;                      // n * nh + head
     const int n = (int)(nhid / nh), hd = (int)(nhid % nh);
     const long ld = 3L * E;
-    const long base = (long)n * S * ld + hd * DH;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
     const long dbase = (long)n * S * E + hd * DH;
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
@@ -712,7 +712,8 @@ bool flash_attn_supported(int S, int E, int nh) {
 }
 
 int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
-                   DropKey drop, int io_bf16, hipStream_t st) {
+                   DropKey drop, int io_bf16, hipStream_t st, long qkv_B) {
+    const int qB = (int)(qkv_B > 0 ? qkv_B : N);
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
     const size_t sm = fwd_smem(S, dh);
@@ -720,7 +721,7 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
 #define GG_FWD(D, B)                                                                                          \
     do {                                                                                                      \
         GG_TRY(set_smem(&attn_fwd_kernel<D, B>, sm));                                                         \
-        hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop); \
+        hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
     } while (0)
     if (io_bf16) {
         if (dh == 64) GG_FWD(64, true);
@@ -737,7 +738,8 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
 }
 
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st) {
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B) {
+    const int qB = (int)(qkv_B > 0 ? qkv_B : N);
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
     const size_t sm = dq_smem(S, dh);
@@ -746,8 +748,8 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
 #define GG_BWD(D, B)                                                                                                        \
     do {                                                                                                                    \
         GG_TRY(set_smem(&attn_bwd_dq_kernel<D, B>, sm));                                                                    \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop); \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items); \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items, qB); \
     } while (0)
     if (io_bf16) {
         if (dh == 64) GG_BWD(64, true);

@@ -78,6 +78,7 @@ struct CondActs {
     LayerActs L[MAXL];
     float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar, *t2i_qt;
     bool sqx = false;          // projection-free single-query T2I attention, generic kernel
+    bool share0 = false;       // dropout replicas share the layer-0 input x0 and its QKV projection (no replicated copy)
     bool sqx2 = false;         // ... streaming kernels with the per-head projections hoisted into batched GEMMs
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
@@ -387,7 +388,7 @@ bool wgrad_film_ok(gg_engine* e, const float* dY, long ldy, const float* X, long
 // dbias: bias gradient (column sums of dY) - folded into the token-reduction kernel when dY is stored in bf16 (the sums
 // then use exactly the stored values), a separate column-sum launch otherwise
 int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                   int dy_bf16 = 0, int x_bf16 = 0, const WgradFilm* film = nullptr, float* dbias = nullptr) {
+                   int dy_bf16 = 0, int x_bf16 = 0, const WgradFilm* film = nullptr, float* dbias = nullptr, long x_mod = 0) {
     gg_engine* e = c.e;
     if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
         e->launches++;
@@ -407,7 +408,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
             r.e1 = e->prof_pool[e->prof_next++];
             GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
         }
-        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr));
+        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr, x_mod));
         if (dbias && !dy_bf16) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, 0)); e->launches++; }
         if (e->prof_on) {
             GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
@@ -415,7 +416,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
         }
         return 0;
     }
-    GG_REQUIRE(!film, "lin_bwd_weight: FiLM operand needs the token-reduction kernel");
+    GG_REQUIRE(!film && x_mod == 0, "lin_bwd_weight: FiLM / repeated-row operands need the token-reduction kernel");
     if (dbias) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, dy_bf16)); e->launches++; }
     GemmP p;
     p.A = dY; p.B = X; p.C = dW; p.M = N; p.N = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw;
@@ -525,14 +526,6 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     }
     KL(k_write_cls(a.x0, w + n.cls, B, S, E, c.st));
     KL(k_build_mask(in->patch_pad, a.mask, B, P, c.st));
-    const float* x_in = a.x0;
-    const float* tok = a.tok;
-    if (R > 1) {
-        KL(k_copy_rows_bcast(a.xrep, a.x0, RB * S, (long)B * S, E, c.st));
-        KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
-        x_in = a.xrep;
-        tok = a.tokrep;
-    }
     const float scale = 1.f / sqrtf((float)dh);
     const bool use_flash = e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(S, E, nh);
     a.flash = use_flash;
@@ -540,19 +533,35 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // must be a tlin / flash kernel, which holds for E in {64,128,256} (see tlin_supported)
     const bool bst = e->bstore_on && use_flash && use_tlin(e) && (E == 64 || E == 128 || E == 256);
     a.bst = bst;
+    // The replicas differ only by their dropout draws, and nothing is dropped before the first attention: the layer-0
+    // input x0 and its QKV projection are the same for all of them.  With the fused kernels (row / sample indices taken
+    // modulo the un-replicated size) neither the R-fold copy of x0 nor R-1 of the R projections exist.
+    const bool share0 = R > 1 && bst && e->wgrad_on && (long)B * S >= 4096;      // (the weight-gradient kernel must engage)
+    a.share0 = share0;
+    const float* x_in = a.x0;
+    const float* tok = a.tok;
+    if (R > 1) {
+        if (!share0) {
+            KL(k_copy_rows_bcast(a.xrep, a.x0, RB * S, (long)B * S, E, c.st));
+            x_in = a.xrep;
+        }
+        KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
+        tok = a.tokrep;
+    }
     for (int l = 0; l < e->nl; ++l) {
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
         {
             TlinP t;
-            t.X = x_in; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
+            const bool shared = share0 && l == 0;
+            t.X = x_in; t.ldx = E; t.M = shared ? (long)B * S : RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
             t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E; t.y_bf16 = bst;
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (use_flash) {
-            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st));
+            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st, share0 && l == 0 ? B : 0));
         } else {
             {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
                 GemmP p;
@@ -579,7 +588,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             TlinP t;
             t.X = L.ctx; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.sa.ow); t.ldw = E; t.bias = w + lp.sa.ob;
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
-            t.res = x_in; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
+            t.res = x_in; t.ldres = E; t.res_rows = (share0 && l == 0) ? (long)B * S : RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
@@ -740,7 +749,8 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     for (int l = e->nl - 1; l >= 0; --l) {
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
-        const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 ? a.xrep : a.x0);
+        const bool shared = a.share0 && l == 0;          // layer-0 input and QKV projection exist once for all replicas
+        const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 && !a.share0 ? a.xrep : a.x0);
         // LN2
         KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
                            dkey(e, a, n.role, l, 3), c.st, bst));
@@ -779,7 +789,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (a.flash) {
-            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st));
+            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0));
             c.e->launches += 2;
         } else {
             const float* Pd = L.P;
@@ -823,7 +833,8 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 GG_TRY(run_gemm(c, p));
             }
         }
-        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb));
+        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb,
+                              shared ? (long)B * S : 0));
         {   // dx_in = dr1 + dqkv Win
             TlinP t;
             t.X = e->sdqkv; t.ldx = 3 * E; t.M = RB * S; t.W = WTB(n, lp.sa.inw); t.ldw = 3 * E;

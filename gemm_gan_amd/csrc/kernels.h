@@ -103,11 +103,13 @@ int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_wei
 bool flash_attn_supported(int S, int E, int nh);
 // qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S].
 // io_bf16: qkv / ctx / dctx / dqkv are bf16 tensors (they only ever feed bf16 MFMA operands), else fp32.
+// qkv_B > 0: qkv holds the projection of the first qkv_B samples only and sample n reads sample n % qkv_B (dropout
+// replicas stacked on the batch axis share the layer-0 projection); outputs are always per sample
 int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
-                   DropKey drop, int io_bf16, hipStream_t st);
+                   DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0);
 // dctx [N,S,E] -> dqkv [N,S,3E] (fully overwritten); delta [N,nh,S] scratch
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st);
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0);
 
 // token-on-lane Linear (tlin.hip): Y[M,N] = epi(X[M,K] W[N,K]^T), bf16 MFMA, activations read once ---------------
 struct TlinP {
@@ -161,7 +163,8 @@ struct WgradFilm { const float* g = nullptr; const float* b = nullptr; long ld =
 // with W [N,K]:  dgamma[b,k] += sum_n W[n,k] C_b[n,k],  dbeta[b,k] += sum_n W[n,k] sum_tokens dY_b[token,n]
 struct WgradFilmGrad { const float* W = nullptr; long ldw = 0; float* dgamma = nullptr; float* dbeta = nullptr; long ld = 0; int tokens = 0; };
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr, float* dbias = nullptr);
+          hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr, float* dbias = nullptr,
+          long x_mod = 0);        // x_mod > 0: X holds x_mod rows, row m is read at m % x_mod
 // dbias (optional): dbias[n] += sum_m dY[m, n] with dY as the kernel sees it (bf16 operand values) - the Linear's bias gradient
 
 // optimiser ---------------------------------------------------------------------------------------

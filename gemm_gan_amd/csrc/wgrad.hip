@@ -55,13 +55,16 @@ struct Stager {
     // Unconditional loads (rows / columns past the end are clamped to valid addresses so nothing branches and all
     // pieces are in flight together); `zero` blanks the out-of-range pieces afterwards - needed for dY only: a zero
     // dY row/column contributes nothing whatever X holds, and out-of-range X columns only feed unstored outputs.
-    __device__ __forceinline__ void load(const void* base, long ld, long tok0, long tok_end, int col0, int cols_valid, int tid, bool zero) {
+    // mod > 0: the operand holds `mod` rows that repeat (replicas sharing one input): row t is read at t % mod
+    __device__ __forceinline__ void load(const void* base, long ld, long tok0, long tok_end, int col0, int cols_valid, int tid, bool zero,
+                                         long mod = 0) {
         if constexpr (BF) {
             const __bf16* p = reinterpret_cast<const __bf16*>(base);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {                        // piece = 8 bf16
                 const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
-                const long t = min(tok0 + row, tok_end - 1);
+                long t = min(tok0 + row, tok_end - 1);
+                if (mod > 0) t %= mod;
                 const int cc = min(8 * pc, cols_valid - 8);
                 r[i] = *reinterpret_cast<const u32x4*>(p + t * ld + col0 + cc);
                 if (zero && (tok0 + row >= tok_end || 8 * pc >= cols_valid)) r[i] = u32x4{0u, 0u, 0u, 0u};
@@ -71,7 +74,8 @@ struct Stager {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {                        // piece = 4 fp32
                 const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
-                const long t = min(tok0 + row, tok_end - 1);
+                long t = min(tok0 + row, tok_end - 1);
+                if (mod > 0) t %= mod;
                 const int cc = min(4 * pc, cols_valid - 4);
                 r[i] = *reinterpret_cast<const u32x4*>(p + t * ld + col0 + cc);
                 if (zero && (tok0 + row >= tok_end || 4 * pc >= cols_valid)) r[i] = u32x4{0u, 0u, 0u, 0u};
@@ -127,7 +131,7 @@ struct Stager {
 template <bool YB, bool XB, bool FILM, bool FGRAD>
 __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
                                                     float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
-                                                    WgradFilmGrad fg, float* __restrict__ dbias) {
+                                                    WgradFilmGrad fg, float* __restrict__ dbias, long x_mod) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
     auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
     auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     for (int d = 0; d < DEPTH; ++d) {
         if (d < nch) {
             sy[d].load(dY, ldy, (c_beg + d) * CT, M, n0, nvalid, tid, true);
-            sx[d].load(X, ldx, (c_beg + d) * CT, M, k0, kvalid, tid, false);
+            sx[d].load(X, ldx, (c_beg + d) * CT, M, k0, kvalid, tid, false, x_mod);
             if constexpr (FILM) sx[d].load_film(film.g, film.b, film.ld, film.group, (c_beg + d) * CT, M, k0, kvalid, tid);
         }
     }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 const int buf = (int)(r & 1);
                 if (r + DEPTH < nch) {
                     sy[u].load(dY, ldy, (c_beg + r + DEPTH) * CT, M, n0, nvalid, tid, true);
-                    sx[u].load(X, ldx, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid, false);
+                    sx[u].load(X, ldx, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid, false, x_mod);
                     if constexpr (FILM) sx[u].load_film(film.g, film.b, film.ld, film.group, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid);
                 }
 #pragma unroll
@@ -281,7 +285,7 @@ bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long 
 }
 
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in, float* dbias) {
+          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in, float* dbias, long x_mod) {
     WgradFilm film;
     if (film_in) film = *film_in;
     WgradFilmGrad fgrad;
@@ -309,7 +313,7 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
     } while (0)
     if (fgrad.W) {
         GG_WG(false, false, false, true);

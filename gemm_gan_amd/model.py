@@ -302,17 +302,48 @@ class WGAN_GP:
         eng.generator_apply(1.0 / w)
         self._publish_gen_loss()
 
+    # ---- losses (R:421-423, R:458-460) -------------------------------------------------------------------------------
+    # The reference publishes disc_loss / gen_loss (0-d tensors) and d_batch_loss / g_batch_loss (numpy) after every call,
+    # with three .item() host syncs per critic iteration.  Here a call leaves a DEVICE snapshot of the engine's loss
+    # slots (an async 24-byte copy on the same stream); the attributes are computed from it when read, so a loop that
+    # does not look at the losses never stalls the host, and one that does (fit(), like the reference) syncs once.
     def _publish_critic_losses(self):
-        l = self.engine.losses.tolist()                                     # one host sync (reference: three, R:421-423)
-        d_real, d_fake, gp = l[L.LOSS_D_REAL], l[L.LOSS_D_FAKE], l[L.LOSS_GP]
-        self.disc_loss = torch.tensor(d_real + d_fake + self.gp_weight * gp, device=self.device)
-        self.d_batch_loss = np.array([d_real + d_fake, d_real, d_fake])
-        self.gp_value = gp
+        self._crit_snap = self.engine.losses.clone()
+        self._crit_host = None
 
     def _publish_gen_loss(self):
-        g = float(self.engine.losses[L.LOSS_G])
-        self.gen_loss = torch.tensor(g, device=self.device)
-        self.g_batch_loss = np.array([g])
+        self._gen_snap = self.engine.losses[L.LOSS_G].clone()
+        self._gen_host = None
+
+    def _crit_values(self):
+        if self._crit_host is None:
+            l = self._crit_snap.tolist()                                    # one host sync (reference: three)
+            self._crit_host = (l[L.LOSS_D_REAL], l[L.LOSS_D_FAKE], l[L.LOSS_GP])
+        return self._crit_host
+
+    @property
+    def disc_loss(self):
+        s = self._crit_snap
+        return s[L.LOSS_D_REAL] + s[L.LOSS_D_FAKE] + self.gp_weight * s[L.LOSS_GP]
+
+    @property
+    def d_batch_loss(self):
+        d_real, d_fake, _ = self._crit_values()
+        return np.array([d_real + d_fake, d_real, d_fake])
+
+    @property
+    def gp_value(self):
+        return self._crit_values()[2]
+
+    @property
+    def gen_loss(self):
+        return self._gen_snap
+
+    @property
+    def g_batch_loss(self):
+        if self._gen_host is None:
+            self._gen_host = float(self._gen_snap)
+        return np.array([self._gen_host])
 
     def train(self, gene_expression, text_token, text_token_padding, patches, padding_mask):
         x, text, tpad, pat, ppad = self._prep(gene_expression, text_token, text_token_padding, patches, padding_mask)
