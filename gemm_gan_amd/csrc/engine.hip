@@ -968,14 +968,15 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
 }
 
 int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses,
-                    const float* x_fake_pre = nullptr) {
+                    const float* x_fake_pre = nullptr) {      // x_fake_pre: generator output computed ahead (its bf16 shadow
+                                                              // weights were refreshed then and the generator is not run here)
     gg_engine* e = c.e;
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H;
     const float slope = e->cfg.negative_slope;
     const int R = e->dropout > 0.f ? 3 : 1;
     GG_REQUIRE(R <= e->maxR, "workspace was sized for dropout == 0; recreate the engine with dropout > 0");
-    GG_TRY(refresh_shadows(c, e->net[GG_ROLE_GENERATOR]));
+    if (!x_fake_pre) GG_TRY(refresh_shadows(c, e->net[GG_ROLE_GENERATOR]));
     GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
     KL(k_fill(D.g, D.total, 0.f, c.st));
