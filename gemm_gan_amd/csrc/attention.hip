@@ -18,6 +18,7 @@
 // Dropout uses the same counter hash and the same element index ((n*nh+h)*S+q)*S+key as the unfused
 // path (kernels.hip), so both paths draw identical masks.
 #include "kernels.h"
+#include <cstdlib>
 #include "drop_rng.h"
 
 namespace gg {
@@ -517,6 +518,211 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, dQ, key-chunked variant: the keys are staged in NCH = 2 chunks, so the LDS images are half as large and
+// TWO workgroups fit a CU (the kernel is VALU-issue bound: a second wave per SIMD is worth ~1.4x).  A wave keeps
+// the dQ accumulators of all its query tiles (at most DQ_SLOTS) across the chunks and reloads their Q / dO
+// fragments per chunk (L2 hits).  Same arithmetic, same dropout stream, same shared left-over tile as above.
+// ------------------------------------------------------------------------------------------------------
+constexpr int DQ_SLOTS = 3;
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const void* __restrict__ qkv, const void* __restrict__ ctx,
+                                                              const void* __restrict__ dctx,
+                                                              const float* __restrict__ lse2, float* __restrict__ delta,
+                                                              const uint8_t* __restrict__ mask, int mask_B,
+                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const int ckt = (nkt + 1) / 2;                  // key tiles per chunk
+    const int CK = ckt * 32;                        // keys per chunk
+    constexpr int LDK = DH + 8;
+    const int LDT = CK + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vs = Ks + CK * LDK;
+    __bf16* Kt = Vs + CK * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Kt + DH * LDT);
+    uint8_t* Mt = Ms + Sp;
+    float* Co = reinterpret_cast<float*>(Mt + 64);
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
+    __syncthreads();
+    for (int t = tid; t < nkt; t += 256) {
+        uint8_t any = 0;
+        for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
+        Mt[t] = any;
+    }
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const bool coop = (nqt % 4 == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;
+    const int nq_main = coop ? nqt - 1 : nqt;
+    const int n_items = nq_main + (coop ? 4 : 0);
+
+    f32x16 dQ[DQ_SLOTS][DT];
+    float L2s[DQ_SLOTS], dls[DQ_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+        L2s[sl] = 0.f; dls[sl] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[sl][dt][i] = 0.f;
+    }
+
+    for (int ch = 0; ch < 2; ++ch) {
+        const int kbase = ch * CK;                               // first key of the chunk
+        const int krows = min(CK, Sp - kbase);                  // staged rows of the chunk (multiple of 32)
+        __syncthreads();                                         // the previous chunk's readers are done (and Mt is written)
+        // rows beyond S are zero-filled by the staging helpers (their S / Sp arguments are chunk-relative)
+        stage_rows<DH, IOB>(Ks, qkv, base + E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), krows, tid, 256);
+        stage_rows<DH, IOB>(Vs, qkv, base + 2 * E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), krows, tid, 256);
+        stage_transposed<DH, IOB>(Kt, qkv, base + E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), CK, tid, 256);
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+            const int it = wave + 4 * sl;
+            if (it >= n_items) continue;
+            const bool shared = it >= nq_main;
+            const int qt = shared ? nqt - 1 : it;
+            const int q = qt * 32 + c;
+            const int qc = min(q, S - 1);
+            bf16x8 qf[KS], df[KS];
+            float dl = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+                qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+                df[s] = load_frag8<IOB>(dctx, off);
+                if (ch == 0) {
+                    float dv[8], ov[8];
+                    load_f32x8<IOB>(dctx, off, dv);
+                    load_f32x8<IOB>(ctx, off, ov);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dl += dv[j] * ov[j];
+                }
+            }
+            if (ch == 0) {
+                dl += __shfl_xor(dl, 32, 64);
+                dls[sl] = dl;
+                L2s[sl] = q < S ? lse2[(long)blockIdx.x * S + q] : 0.f;
+                if (q < S && h == 0 && (!shared || wave == 0)) delta[(long)blockIdx.x * S + q] = dl;
+            }
+            dl = dls[sl];
+            const float L2 = L2s[sl];
+            const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+            // key tiles of this chunk; the shared tile takes every 4th GLOBAL tile index
+            const int kt_lo = ch * ckt, kt_hi = min(nkt, kt_lo + ckt);
+            int kt = kt_lo;
+            int kstep = 1;
+            if (shared) {
+                kstep = 4;
+                kt = kt_lo + ((wave - kt_lo) % 4 + 4) % 4;
+            }
+            for (; kt < kt_hi; kt += kstep) {
+                const int lr = (kt - kt_lo) * 32;                 // first LDS row of the tile
+                f32x16 s16, dp16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (lr + c) * LDK + 16 * s + 8 * h);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (lr + c) * LDK + 16 * s + 8 * h);
+                    s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+                    dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
+                }
+                if (drop.p > 0.f) {
+                    const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                        dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                        dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                        dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                        dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt * 32 + acc_row(i, h);
+                        const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
+                        s16[i] = p * (dp16[i] - dl) * scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(s16[i] * sc - L2) * (dp16[i] - dl) * scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8 kf = frag_transposed(Kt, LDT, min(dt * 32 + c, DH - 1), lr, s2, h);
+                        dQ[sl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[sl][dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- outputs -------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+        const int it = wave + 4 * sl;
+        const bool live = it < n_items;
+        const bool shared = live && it >= nq_main;
+        const int qt = shared ? nqt - 1 : it;
+        const int q = qt * 32 + c;
+        // the shared tile sits in the same slot of every wave (nq_main % 4 == 0), so this barrier is uniform
+        if (coop && 4 * sl + 0 >= nq_main && 4 * sl < nq_main + 4) {
+            if (wave != 0 && q < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) part[d] = dQ[sl][dt][i];
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (q < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (DH + 2);
+                constexpr int WS = CO_MAXQ * (DH + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = min(dt * 32 + acc_row(i, h), DH - 1);
+                        dQ[sl][dt][i] += p0[d] + p0[WS + d] + p0[2 * WS + d];
+                    }
+            }
+        }
+        if (live && q < S) {
+            const long out = ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {dQ[sl][dt][4 * g], dQ[sl][dt][4 * g + 1], dQ[sl][dt][4 * g + 2], dQ[sl][dt][4 * g + 3]};
+                        store4<IOB>(dqkv, out + d, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, dK / dV: keys on the lanes.  One WAVE per (sample, head, 32-key tile) - no workgroup barriers.
 // The wave keeps K, V fragments of its key tile and the dK^T, dV^T [dh x 32 keys] accumulators in
 // registers and walks all query tiles.  Per query tile it loads its 32 rows of Q and dO once: the packed
@@ -696,6 +902,11 @@ size_t dq_smem(int S, int DH) {
     return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 
+size_t dq2_smem(int S, int DH) {
+    const int Sp = (S + 31) / 32 * 32;
+    const int CK = ((Sp / 32 + 1) / 2) * 32;
+    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
+}
 template <typename K>
 int set_smem(K kernel, size_t bytes) {
     GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -745,10 +956,22 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     const size_t sm = dq_smem(S, dh);
     const dim3 grid((unsigned)(N * nh));
     const long items = N * nh * ((S + 31) / 32);       // one wave per (sample, head, key tile)
+    // key-chunked dQ variant: two workgroups per CU when a wave has at most DQ_SLOTS query tiles and the halves fit
+    const int nqt_ = (S + 31) / 32;
+    const bool coop_ = (nqt_ % 4 == 1) && nqt_ > 1 && (S - 32 * (nqt_ - 1)) <= CO_MAXQ;
+    const int items_q = (coop_ ? nqt_ - 1 : nqt_) + (coop_ ? 4 : 0);
+    const size_t sm2 = dq2_smem(S, dh);
+    static const bool dq2_off = getenv("GG_ATTN_DQ1") != nullptr;
+    const bool use_dq2 = !dq2_off && nqt_ >= 2 && items_q <= 4 * DQ_SLOTS && 2 * sm2 <= 160 * 1024;
 #define GG_BWD(D, B)                                                                                                        \
     do {                                                                                                                    \
-        GG_TRY(set_smem(&attn_bwd_dq_kernel<D, B>, sm));                                                                    \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+        if (use_dq2) {                                                                                                      \
+            GG_TRY(set_smem(&attn_bwd_dq2_kernel<D, B>, sm2));                                                              \
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<D, B>), grid, dim3(256), sm2, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+        } else {                                                                                                            \
+            GG_TRY(set_smem(&attn_bwd_dq_kernel<D, B>, sm));                                                                \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+        }                                                                                                                   \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items, qB); \
     } while (0)
     if (io_bf16) {
