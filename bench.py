@@ -94,7 +94,7 @@ def log(msg):
 
 def cpu_baseline(args):
     """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
-    bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 3 timed train() steps."""
+    bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 12 timed train() steps (about 20 s)."""
     from oracle.torch_oracle import PathConfig, Trainer, synthetic_batch
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -111,7 +111,7 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     step()
     warm = time.perf_counter() - t0
-    n = max(1, min(3, int(20.0 / max(warm, 1e-3))))
+    n = max(1, min(12, int(20.0 / max(warm, 1e-3))))      # about 20 s of CPU work
     log(f"cpu baseline: warm-up step {warm:.1f} s on {cores} threads, timing {n} step(s)")
     t0 = time.perf_counter()
     for _ in range(n):
