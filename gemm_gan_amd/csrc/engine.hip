@@ -147,6 +147,7 @@ struct gg_engine {
     hipStream_t st = nullptr;
     // live profiling
     bool prof_on = false;
+    unsigned prof_mask = 0xffffffffu;      // kernel classes that get event pairs (bit = class id)
     struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -320,7 +321,8 @@ int run_gemm(Ctx& c, const GemmP& p) {
     e->launches++;
     const bool bf16 = e->precision == GG_PREC_BF16;
     const bool small = bf16 && e->small_on && gemm_small_wanted(p);
-    if (!e->prof_on) return small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
+    const int cls_ = small ? 11 : p.layA * 2 + p.layB + (bf16 ? 4 : 0);
+    if (!e->prof_on || !((e->prof_mask >> cls_) & 1u)) return small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
     if (e->prof_next + 2 > e->prof_pool.size()) {
         for (int i = 0; i < 4096; ++i) {
             hipEvent_t ev;
@@ -393,7 +395,8 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
     if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
         e->launches++;
         gg_engine::ProfRec r;
-        if (e->prof_on) {
+        const bool prof = e->prof_on && ((e->prof_mask >> 10) & 1u);
+        if (prof) {
             if (e->prof_next + 2 > e->prof_pool.size()) {
                 for (int i = 0; i < 4096; ++i) {
                     hipEvent_t ev;
@@ -410,7 +413,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
         }
         GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr, x_mod));
         if (dbias && !dy_bf16) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, 0)); e->launches++; }
-        if (e->prof_on) {
+        if (prof) {
             GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
             e->prof_recs.push_back(r);
         }
@@ -448,7 +451,8 @@ inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    //
 int try_tlin(Ctx& c, const TlinP& p) {
     if (!use_tlin(c.e) || !tlin_supported(p)) return 0;
     c.e->launches++;
-    if (c.e->prof_on) {
+    const int tcls = 8 + ((p.ln_g || p.res || p.K > 256) ? 1 : 0);
+    if (c.e->prof_on && ((c.e->prof_mask >> tcls) & 1u)) {
         gg_engine* e = c.e;
         if (e->prof_next + 2 > e->prof_pool.size()) {
             for (int i = 0; i < 4096; ++i) {
@@ -1305,8 +1309,9 @@ int gg_set_optimizer_step(gg_engine* e, int role, int step) {
 int64_t gg_launch_count(const gg_engine* e) { return e ? e->launches : -1; }
 
 int gg_profile_enable(gg_engine* e, int on) {
-    GG_REQUIRE(e, "null argument");
+    GG_REQUIRE(e && on >= 0, "bad argument");
     e->prof_on = on != 0;
+    e->prof_mask = on > 1 ? (unsigned)on >> 1 : 0xffffffffu;      // on = 1 | (class bit mask << 1) restricts the classes
     if (on) { e->prof_recs.clear(); e->prof_next = 0; }
     return 0;
 }

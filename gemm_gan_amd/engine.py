@@ -193,8 +193,19 @@ class Engine:
             raise RuntimeError(f"hipMemcpy failed: {rc}")
         return out.float()
 
-    def profile(self, on: bool):
-        L.check(self.lib.gg_profile_enable(self.h, int(on)))
+    PROFILE_CLASSES = ["gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
+                       "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>",
+                       "tlin_kernel<64,stream>", "tlin_kernel<32,resident>", "wgrad_kernel", "gemm_small_kernel"]
+
+    def profile(self, on: bool, classes=None):
+        """HIP-event pair around every GEMM-class launch (classes=None) or only around the named classes."""
+        arg = int(bool(on))
+        if on and classes:
+            mask = 0
+            for c in classes:
+                mask |= 1 << self.PROFILE_CLASSES.index(c)
+            arg = 1 | (mask << 1)
+        L.check(self.lib.gg_profile_enable(self.h, arg))
 
     def profile_collect(self):
         """[{name, launches, ms, flops, bytes}] per kernel class since profile(True)."""

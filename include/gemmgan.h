@@ -168,6 +168,8 @@ int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel);
 int gg_debug_buffer_is_bf16(gg_engine* e, const char* name);   /* 1 if that buffer currently holds bf16 elements */
 /* ---- live per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ---------
  * gg_profile_enable(e, 1) brackets every subsequent GEMM launch with an event pair taken from a pool;
+ * gg_profile_enable(e, 1 | (mask << 1)) only the launches of the kernel classes whose bit is set in mask (bit i = row i of
+ * the aggregate), so that a timed region can carry the events of ONE class without paying for all of them;
  * gg_profile_collect synchronises the events and aggregates per kernel class (= kernel symbol:
  * "gemm_f32<A-layout,B-layout>") launches, total milliseconds, algorithmic FLOPs (2*M*N*K*batch) and
  * algorithmic bytes ((M*K + K*N + M*N)*4*batch).  gg_profile_read returns row i of the aggregate. */
