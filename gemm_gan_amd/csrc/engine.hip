@@ -15,6 +15,7 @@
 #include "../../include/gemmgan.h"
 #include "gg_common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gg {
 static thread_local std::string g_err;
@@ -139,6 +140,11 @@ struct gg_engine {
     int small_on = 1;          // latency-optimised kernel for few-tile GEMMs (bf16 mode)
     int wgrad_on = 1;          // dedicated long-reduction weight-gradient kernel (bf16 mode)
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
+    // weight gradients are leaves of the backward chain: they run on a second stream beside the data-gradient kernels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
+    bool side_pending[3] = {false, false, false};
+    int side_on = 1;
     int prefetch_on = 1;       // gg_train_step computes the generator outputs of all critic iterations in batched passes
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
@@ -673,6 +679,40 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
 // conditioning stack backward   [numpy_oracle.cond_bwd]
 // dc: [Rb*B, E] gradient w.r.t. the conditioning vector of the first Rb replicas
 // ------------------------------------------------------------------------------------------------
+// ---- second stream for the encoder weight gradients ---------------------------------------------------------------
+// dW = dY^T X reads two buffers the main chain has just produced and writes only the gradient buffer, which nothing on
+// the main stream touches until the optimiser: it overlaps with the data-gradient kernels that follow (their tails
+// and bubbles get filled).  side_begin: the side stream waits for everything enqueued so far on the caller's stream;
+// side_end(slot): marks the launch; side_wait(slot): the caller's stream waits for it - called before the kernel that
+// OVERWRITES a buffer the pending launch reads (slot 0: sdres, 1: sdh, 2: sdqkv) and at the end of the backward.
+bool side_begin(Ctx& c, Ctx& cs) {
+    gg_engine* e = c.e;
+    static const bool env_off = getenv("GG_NO_SIDE_WGRAD") != nullptr;
+    cs = c;
+    if (!e->side_on || env_off) return false;
+    if (!e->side) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) return false;
+        bool ok = hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 3; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { e->side_on = 0; return false; }
+    }
+    if (hipEventRecord(e->ev_ready, c.st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_ready, 0) != hipSuccess) return false;
+    cs.st = e->side;
+    return true;
+}
+int side_end(Ctx& c, bool forked, int slot) {
+    if (!forked) return 0;
+    GG_CHECK_HIP(hipEventRecord(c.e->ev_done[slot], c.e->side));
+    c.e->side_pending[slot] = true;
+    return 0;
+}
+int side_wait(Ctx& c, int slot) {
+    if (!c.e->side_pending[slot]) return 0;
+    GG_CHECK_HIP(hipStreamWaitEvent(c.st, c.e->ev_done[slot], 0));
+    c.e->side_pending[slot] = false;
+    return 0;
+}
+
 int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* dc, int Rb) {
     gg_engine* e = c.e;
     const int B = a.B, P = a.P, T = a.T, S = P + 1, E = e->E, F = e->F, nh = e->nh, dh = e->dh;
@@ -756,10 +796,17 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         const bool shared = a.share0 && l == 0;          // layer-0 input and QKV projection exist once for all replicas
         const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 && !a.share0 ? a.xrep : a.x0);
         // LN2
+        GG_TRY(side_wait(c, 0));
         KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
                            dkey(e, a, n.role, l, 3), c.st, bst));
         // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))   (db2 = column sums of df: fused above)
-        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F, bst, bst));
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F, bst, bst));
+            GG_TRY(side_end(c, fk, 0));
+        }
+        GG_TRY(side_wait(c, 1));
         {   // dhpre = (df W2) * [h > 0] / (1-p) : the stored post-dropout h gates both ReLU and the kept-mask
             TlinP t;
             t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.l2w); t.ldw = E;
@@ -771,7 +818,12 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 KL(k_act_bwd(e->sdh, L.h, RB * S * F, 0.f, ks, c.st));
             });
         }
-        GG_TRY(lin_bwd_weight(c, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0, nullptr, g + lp.l1b));
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0, nullptr, g + lp.l1b));
+            GG_TRY(side_end(c, fk, 1));
+        }
         {   // dx1 = dr2 + dhpre W1
             TlinP t;
             t.X = e->sdh; t.ldx = F; t.M = RB * S; t.W = WTB(n, lp.l1w); t.ldw = F;
@@ -780,10 +832,16 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1)));
         }
         // LN1
+        GG_TRY(side_wait(c, 0));
         KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
                            dkey(e, a, n.role, l, 1), c.st, bst));
         // self attention out-proj   (d(out_proj.bias) fused above)
-        GG_TRY(lin_bwd_weight(c, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
+            GG_TRY(side_end(c, fk, 0));
+        }
         {
             TlinP t;
             t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.sa.ow); t.ldw = E;
@@ -792,6 +850,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
+        GG_TRY(side_wait(c, 2));
         if (a.flash) {
             KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0));
             c.e->launches += 2;
@@ -837,8 +896,13 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                 GG_TRY(run_gemm(c, p));
             }
         }
-        GG_TRY(lin_bwd_weight(c, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb,
-                              shared ? (long)B * S : 0));
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb,
+                                  shared ? (long)B * S : 0));
+            GG_TRY(side_end(c, fk, 2));
+        }
         {   // dx_in = dr1 + dqkv Win
             TlinP t;
             t.X = e->sdqkv; t.ldx = 3 * E; t.M = RB * S; t.W = WTB(n, lp.sa.inw); t.ldw = 3 * E;
@@ -847,6 +911,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
         }
     }
+    for (int i = 0; i < 3; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
     const float* dx0 = dx;
     const float* dtok = e->s_dtokrep;
@@ -1126,7 +1191,16 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     return 0;
 }
 
-void gg_destroy(gg_engine* e) { delete e; }
+void gg_destroy(gg_engine* e) {
+    if (!e) return;
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        (void)hipEventDestroy(e->ev_ready);
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e->ev_done[i]);
+        (void)hipStreamDestroy(e->side);
+    }
+    delete e;
+}
 
 int gg_param_count(const gg_engine* e, int role) { return e && (role == 0 || role == 1) ? (int)e->net[role].ps.size() : -1; }
 const char* gg_param_name(const gg_engine* e, int role, int i) {
