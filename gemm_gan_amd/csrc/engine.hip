@@ -911,7 +911,6 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
         }
     }
-    for (int i = 0; i < 3; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
     const float* dx0 = dx;
     const float* dtok = e->s_dtokrep;
@@ -927,7 +926,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         // dW_pe += demb^T (gamma * patches + beta): the modulation is applied while the token chunks are staged
         WgradFilm f;
         f.g = a.gb; f.b = a.gb + Dp; f.ld = 2 * Dp; f.group = P;
-        GG_TRY(lin_bwd_weight(c, e->s_demb, E, in->patches, Dp, g + n.pe_w, Dp, B * P, E, Dp, 0, 0, &f));
+        GG_TRY(side_wait(c, 1));
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);          // beside the FiLM-gradient contraction below, which reads the same operands
+        GG_TRY(lin_bwd_weight(cs, e->s_demb, E, in->patches, Dp, g + n.pe_w, Dp, B * P, E, Dp, 0, 0, &f));
+        GG_TRY(side_end(c, fk, 1));
     } else {
         KL(k_film_mod(in->patches, a.gb, e->s_mod, B, P, Dp, c.st));
         GG_TRY(lin_bwd_weight(c, e->s_demb, E, e->s_mod, Dp, g + n.pe_w, Dp, B * P, E, Dp));
@@ -951,6 +954,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));
     GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
     KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
+    for (int i = 0; i < 3; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     return 0;
 }
 
