@@ -142,8 +142,8 @@ struct gg_engine {
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     // weight gradients are leaves of the backward chain: they run on a second stream beside the data-gradient kernels
     hipStream_t side = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
-    bool side_pending[3] = {false, false, false};
+    hipEvent_t ev_ready = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool side_pending[4] = {false, false, false, false};
     int side_on = 1;
     int prefetch_on = 1;       // gg_train_step computes the generator outputs of all critic iterations in batched passes
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
@@ -684,7 +684,8 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
 // the main stream touches until the optimiser: it overlaps with the data-gradient kernels that follow (their tails
 // and bubbles get filled).  side_begin: the side stream waits for everything enqueued so far on the caller's stream;
 // side_end(slot): marks the launch; side_wait(slot): the caller's stream waits for it - called before the kernel that
-// OVERWRITES a buffer the pending launch reads (slot 0: sdres, 1: sdh, 2: sdqkv) and at the end of the backward.
+// OVERWRITES a buffer the pending launch reads (slot 0: sdres, 1: sdh, 2: sdqkv; 3: head / gradient-penalty parameter
+// gradients, whose operands live until the next iteration) and at the end of the backward.
 bool side_begin(Ctx& c, Ctx& cs) {
     gg_engine* e = c.e;
     static const bool env_off = getenv("GG_NO_SIDE_WGRAD") != nullptr;
@@ -693,7 +694,7 @@ bool side_begin(Ctx& c, Ctx& cs) {
     if (!e->side) {
         if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) return false;
         bool ok = hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 3; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { e->side_on = 0; return false; }
     }
     if (hipEventRecord(e->ev_ready, c.st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_ready, 0) != hipSuccess) return false;
@@ -954,7 +955,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));
     GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
     KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
-    for (int i = 0; i < 3; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
+    for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     return 0;
 }
 
@@ -986,22 +987,33 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
     const float slope = e->cfg.negative_slope;
     float* dh2 = e->dA;
     float* dh1 = e->dB;
+    // The parameter gradients are leaves (their operands dout / dh2 / dh1 / activations are not rewritten before the
+    // backward's final join): they go to the side stream, the data-gradient chain continues on the caller's.
     if (param_grads) {
-        GG_TRY(lin_bwd_weight(c, dout, OUT, a2, H, g + n.w3, H, rows, OUT, H));
-        if (out_bias_grad) KL(k_colsum(dout, rows, OUT, OUT, g + n.b3, c.st));
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, dout, OUT, a2, H, g + n.w3, H, rows, OUT, H));
+        if (out_bias_grad) { GG_TRY(k_colsum(dout, rows, OUT, OUT, g + n.b3, cs.st)); e->launches++; }
+        GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));
     KL(k_act_bwd(dh2, a2, (long)rows * H, slope, 1.f, c.st));
     if (param_grads) {
-        GG_TRY(lin_bwd_weight(c, dh2, H, a1, H, g + n.w2, H, rows, H, H));
-        KL(k_colsum(dh2, rows, H, H, g + n.b2, c.st));
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, dh2, H, a1, H, g + n.w2, H, rows, H, H));
+        GG_TRY(k_colsum(dh2, rows, H, H, g + n.b2, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_bwd_data(c, dh2, H, w + n.w2, H, dh1, H, rows, H, H));
     KL(k_act_bwd(dh1, a1, (long)rows * H, slope, 1.f, c.st));
     if (param_grads) {
-        GG_TRY(lin_bwd_weight(c, dh1, H, vin, V, g + n.w1, V + E, rows, H, V));
-        GG_TRY(lin_bwd_weight(c, dh1, H, cvec, E, g + n.w1 + V, V + E, rows, H, E));
-        KL(k_colsum(dh1, rows, H, H, g + n.b1, c.st));
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, dh1, H, vin, V, g + n.w1, V + E, rows, H, V));
+        GG_TRY(lin_bwd_weight(cs, dh1, H, cvec, E, g + n.w1 + V, V + E, rows, H, E));
+        GG_TRY(k_colsum(dh1, rows, H, H, g + n.b1, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
     }
     if (dcond) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1 + V, V + E, dcond, E, rows, H, E));
     if (dv) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1, V + E, dv, V, rows, H, V));
@@ -1083,11 +1095,21 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     KL(k_gp_coef(e->gp_nrm2, e->gp_coef, losses, B, e->cfg.gp_weight, c.st));
     KL(k_copy(e->gp_g1s, e->gp_g1, (long)B * H, c.st));
     KL(k_rowscale(e->gp_g1s, e->gp_coef, B, H, c.st));
-    GG_TRY(lin_bwd_weight(c, e->gp_g1s, H, e->gp_grad, G, D.g + D.w1, G + E, B, H, G));    // dW1x += (coef g1)^T grad
+    {
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->gp_g1s, H, e->gp_grad, G, D.g + D.w1, G + E, B, H, G));    // dW1x += (coef g1)^T grad
+        GG_TRY(side_end(c, fk, 3));
+    }
     GG_TRY(lin_fwd(c, e->gp_grad, G, D.w + D.w1, G + E, nullptr, e->gp_dg1, H, B, H, G)); // grad W1x^T
     KL(k_rowscale(e->gp_dg1, e->gp_coef, B, H, c.st));                                     // dg1 = s W1x^T
     KL(k_act_bwd(e->gp_dg1, a1h, (long)B * H, slope, 1.f, c.st));                          // du = m1 * dg1
-    GG_TRY(lin_bwd_weight(c, e->gp_g2, H, e->gp_dg1, H, D.g + D.w2, H, B, H, H));         // dW2 += g2^T du
+    {
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->gp_g2, H, e->gp_dg1, H, D.g + D.w2, H, B, H, H));         // dW2 += g2^T du
+        GG_TRY(side_end(c, fk, 3));
+    }
     GG_TRY(lin_fwd(c, e->gp_dg1, H, D.w + D.w2, H, nullptr, e->gp_dg2, H, B, H, H));     // dg2 = du W2^T
     KL(k_colsum_masked(e->gp_dg2, a2h, B, H, slope, D.g + D.w3, c.st));                    // dw3 += sum m2*dg2
     // ---- conditioning backward for the rows that carry gradient --------------------------------------
@@ -1200,7 +1222,7 @@ void gg_destroy(gg_engine* e) {
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         (void)hipEventDestroy(e->ev_ready);
-        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e->ev_done[i]);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e->ev_done[i]);
         (void)hipStreamDestroy(e->side);
     }
     delete e;
