@@ -728,20 +728,40 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const int bst = a.bst ? 1 : 0;
 
     // ---- I2T backward: t = out_proj(ctx); scores over text tokens; q from p -----------------------
-    GG_TRY(lin_bwd_weight(c, dc, E, a.i2t_ctx, E, g + n.i2t.ow, E, (int)RB, E, E));
-    KL(k_colsum(dc, RB, E, E, g + n.i2t.ob, c.st));
+    {   // parameter-gradient leaves: side stream (see side_begin)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, dc, E, a.i2t_ctx, E, g + n.i2t.ow, E, (int)RB, E, E));
+        GG_TRY(k_colsum(dc, RB, E, E, g + n.i2t.ob, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_tmpE, E, (int)RB, E, E));
     KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
-    GG_TRY(lin_bwd_weight(c, e->s_dq, E, a.t2i_out, E, g + n.i2t.inw, E, (int)RB, E, E));
-    KL(k_colsum(e->s_dq, RB, E, E, g + n.i2t.inb, c.st));
+    {   // parameter-gradient leaves: side stream (see side_begin)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->s_dq, E, a.t2i_out, E, g + n.i2t.inw, E, (int)RB, E, E));
+        GG_TRY(k_colsum(e->s_dq, RB, E, E, g + n.i2t.inb, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     KL(k_copy(e->s_dp, dc, RB * E, c.st));                                        // c = t + p
     GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.i2t.inw, E, e->s_dp, E, (int)RB, E, E, 1));
-    GG_TRY(lin_bwd_weight(c, e->s_dkv2, 2 * E, tok, E, g + n.i2t.inw + (long)E * E, E, (int)(RB * T), 2 * E, E));
-    KL(k_colsum(e->s_dkv2, RB * T, 2 * E, 2 * E, g + n.i2t.inb + E, c.st));
+    {   // parameter-gradient leaves: side stream (see side_begin)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->s_dkv2, 2 * E, tok, E, g + n.i2t.inw + (long)E * E, E, (int)(RB * T), 2 * E, E));
+        GG_TRY(k_colsum(e->s_dkv2, RB * T, 2 * E, 2 * E, g + n.i2t.inb + E, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
     // ---- T2I backward ---------------------------------------------------------------------------------
-    GG_TRY(lin_bwd_weight(c, e->s_dp, E, a.t2i_ctx, E, g + n.t2i.ow, E, (int)RB, E, E));
-    KL(k_colsum(e->s_dp, RB, E, E, g + n.t2i.ob, c.st));
+    {   // parameter-gradient leaves: side stream (see side_begin)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->s_dp, E, a.t2i_ctx, E, g + n.t2i.ow, E, (int)RB, E, E));
+        GG_TRY(k_colsum(e->s_dp, RB, E, E, g + n.t2i.ob, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     GG_TRY(lin_bwd_data(c, e->s_dp, E, w + n.t2i.ow, E, e->s_tmpE, E, (int)RB, E, E));
     if (a.sqx || a.sqx2) {
         if (a.sqx2) {
@@ -758,24 +778,30 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             v.A = e->s_dqt; v.lda = (long)nh * E; v.layA = LAY_KC; v.sAo = E;
             v.B = w + n.t2i.inw + (long)E * E; v.ldb = E; v.layB = LAY_KC; v.sBo = (long)dh * E;
             v.C = e->s_dq; v.ldc = E; v.sCo = dh;
+            GG_TRY(side_wait(c, 3));              // the I2T in-projection gradient on the side stream still reads the first s_dq
             GG_TRY(run_gemm(c, v));
         } else {
+            GG_TRY(side_wait(c, 3));
             KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq, e->s_dqt, (int)RB, S, E, nh, c.st));
         }
-        {   // dWk_h += q_h (x) dqt_h  and  dWv_h += dctx_h (x) xbar_h, summed over the batch (per-head small GEMMs)
+        {   // dWk_h += q_h (x) dqt_h  and  dWv_h += dctx_h (x) xbar_h, summed over the batch (per-head small GEMMs); leaves
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
             GemmP p;
             p.M = dh; p.N = E; p.K = (int)RB; p.layA = LAY_KS; p.layB = LAY_KS; p.lda = E; p.ldb = (long)nh * E; p.ldc = E;
             p.batch = nh; p.batch_inner = 1; p.sAo = dh; p.sBo = E; p.sCo = (long)dh * E; p.accumulate = 1;
             p.A = a.t2i_q; p.B = e->s_dqt; p.C = g + n.t2i.inw + (long)E * E;
-            GG_TRY(run_gemm(c, p));
+            GG_TRY(run_gemm(cs, p));
             p.A = e->s_tmpE; p.B = a.t2i_xbar; p.C = g + n.t2i.inw + 2L * E * E;
-            GG_TRY(run_gemm(c, p));
+            GG_TRY(run_gemm(cs, p));
+            GG_TRY(k_colsum(e->s_tmpE, RB, E, E, g + n.t2i.inb + 2 * E, cs.st)); e->launches++;         // d(bv) = sum dctx ; d(bk) == 0
+            GG_TRY(lin_bwd_weight(cs, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+            GG_TRY(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, cs.st)); e->launches++;
+            GG_TRY(side_end(c, fk, 3));
         }
-        KL(k_colsum(e->s_tmpE, RB, E, E, g + n.t2i.inb + 2 * E, c.st));          // d(bv) = sum dctx ; d(bk) == 0
-        GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
-        KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
         GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
     } else {
+        GG_TRY(side_wait(c, 3));                  // s_dq is rewritten: the I2T in-projection gradient on the side stream reads it
         KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
         GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
         KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
