@@ -1192,8 +1192,19 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
     GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
     KL(k_fill(Gn.g, Gn.total, 0.f, c.st));
-    GG_TRY(generator_forward(c, z, in, e->X2, 1));                       // R:441 (activations kept in actsG/headG)
-    GG_TRY(cond_forward(c, D, in, e->actsD, 1, e->dropout, 0));          // R:449 (frozen critic: forward only)
+    // The generator's forward (R:441, activations kept in actsG/headG) and the frozen critic's conditioning forward (R:449,
+    // forward only) do not depend on each other: the critic's runs on the side stream (both are one-replica passes whose
+    // launches leave most of the chip idle on their own).  Only with the fused attention path: the unfused one shares
+    // a softmax scratch buffer between the networks.
+    {
+        Ctx cs = c;
+        bool fk = false;
+        if (e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(in->P + 1, E, e->nh)) fk = side_begin(c, cs);
+        GG_TRY(cond_forward(cs, D, in, e->actsD, 1, e->dropout, 0));
+        GG_TRY(side_end(c, fk, 3));
+        GG_TRY(generator_forward(c, z, in, e->X2, 1));
+        GG_TRY(side_wait(c, 3));
+    }
     GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->headD.a1, H, B, H, G));
     GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, e->headD.out, 1, B, B));
     KL(k_gen_loss_seed(e->headD.out, e->dseed, losses, B, c.st));
