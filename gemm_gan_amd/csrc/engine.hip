@@ -120,11 +120,17 @@ struct gg_engine {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    CondActs actsG, actsD;
-    HeadActs headG, headD;
+    CondActs actsG, actsD, actsP;      // actsP: generator passes of the pipelined prefetch
+    HeadActs headG, headD, headP;
+    float* c3P = nullptr;
     float *X2;                 // [2B, G]: fake rows then real rows
     float *Xpre = nullptr;     // [GG_MAX_PREFETCH, B, G]: generator outputs of a whole train() computed in batched passes
     int pre_n = 0, pre_next = 0, pre_B = 0;
+    // pipelined prefetch: all but the first output are computed on a third stream in their own activation arena, beside
+    // the critic iterations that do not need them yet; pre_ev[k] marks output k ready (pre_wait[k]: not yet waited for)
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t pre_fork = nullptr, pre_ev[GG_MAX_PREFETCH] = {};
+    bool pre_wait[GG_MAX_PREFETCH] = {};
     float *c3;                 // [3B, E] conditioning rows for the critic head (fake, real, hat)
     float *Pfr;                // [2B, H] x @ W1x^T for fake / real
     float *dseed;              // [2B]
@@ -266,6 +272,7 @@ size_t carve(gg_engine* e, void* base) {
     const long P = e->maxP, Dp = e->Dp;
     carve_cond(e, a, e->actsG, 1);
     carve_cond(e, a, e->actsD, (int)R);
+    carve_cond(e, a, e->actsP, (int)R);
     for (int r = 0; r < 2; ++r) {
         Net& n = e->net[r];
         n.wb = a.take<char>((size_t)n.total * 2);
@@ -274,6 +281,8 @@ size_t carve(gg_engine* e, void* base) {
     }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
+    e->headP.a1 = a.take<float>(3 * B * H); e->headP.a2 = a.take<float>(3 * B * H); e->headP.out = nullptr;
+    e->c3P = a.take<float>(3 * B * E);
     e->X2 = a.take<float>(2 * B * G);
     e->Xpre = a.take<float>((long)GG_MAX_PREFETCH * B * G);
     e->c3 = a.take<float>(3 * B * E);
@@ -1153,34 +1162,87 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
 // run here as dropout replicas stacked on the batch axis - up to maxR at a time, in the critic's activation arena, which
 // is idle before the first critic iteration - instead of n one-replica passes (fewer, larger launches; better tails).
 // Statistically identical to the sequential order: every replica draws its own dropout masks and uses its own z.
-int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
+// one batched generator pass for outputs [first, first + r): conditioning stack in `acts`, head in `head` / `c3`
+int prefetch_chunk(Ctx& c, const float* z_all, int first, int r, const gg_cond* in, CondActs& acts, HeadActs& head, float* c3) {
     gg_engine* e = c.e;
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     const int B = in->B, G = e->G, E = e->E, H = e->H, Lz = e->L;
+    const int rc = e->dropout > 0.f ? r : 1;                                // without dropout the conditioning replicas coincide
+    GG_TRY(cond_forward(c, Gn, in, acts, rc, e->dropout, 0));
+    const float* cvec = acts.c;
+    if (rc == 1 && r > 1) {
+        KL(k_copy_rows_bcast(c3, acts.c, (long)r * B, B, E, c.st));
+        cvec = c3;
+    }
+    GG_TRY(lin_fwd(c, z_all + (long)first * B * Lz, Lz, Gn.w + Gn.w1, Lz + E, nullptr, head.a1, H, r * B, H, Lz));
+    GG_TRY(head_finish(c, Gn, cvec, head.a1, head.a2, e->Xpre + (long)first * B * G, G, r * B, r * B));
+    return 0;
+}
+int prefetch_drain(Ctx& c) {        // the caller's stream waits for every output that is still being computed
+    gg_engine* e = c.e;
+    for (int k = 0; k < GG_MAX_PREFETCH; ++k)
+        if (e->pre_wait[k]) {
+            GG_CHECK_HIP(hipStreamWaitEvent(c.st, e->pre_ev[k], 0));
+            e->pre_wait[k] = false;
+        }
+    return 0;
+}
+int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
+    gg_engine* e = c.e;
+    Net& Gn = e->net[GG_ROLE_GENERATOR];
+    const int B = in->B;
+    GG_TRY(prefetch_drain(c));
     e->pre_n = 0; e->pre_next = 0; e->pre_B = B;
     n = std::min(n, GG_MAX_PREFETCH);
     if (n < 1) return 0;
     GG_TRY(refresh_shadows(c, Gn));
-    int done = 0;
-    while (done < n) {
-        const int r = std::min(n - done, e->dropout > 0.f ? e->maxR : 3);      // head scratch (critic's) holds 3B rows
-        const int rc = e->dropout > 0.f ? r : 1;                                // without dropout the conditioning replicas coincide
-        GG_TRY(cond_forward(c, Gn, in, e->actsD, rc, e->dropout, 0));
-        const float* cvec = e->actsD.c;
-        if (rc == 1 && r > 1) {
-            KL(k_copy_rows_bcast(e->c3, e->actsD.c, (long)r * B, B, E, c.st));
-            cvec = e->c3;
+    const int rmax = e->dropout > 0.f ? e->maxR : 3;                        // head scratch holds 3B rows
+    // Pipelined form (fused attention path only: the unfused one shares a softmax scratch buffer between arenas): the
+    // first output is needed at once and is computed alone on the caller's stream; the others run on a third stream in
+    // their own arena while the critic iterations that do not need them yet proceed.
+    static const bool pipe_off = getenv("GG_NO_PREFETCH_PIPE") != nullptr;
+    bool pipe = !pipe_off && n > 1 && e->side_on && e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(in->P + 1, e->E, e->nh);
+    if (pipe && !e->pre_stream) {
+        bool ok = hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&e->pre_fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < GG_MAX_PREFETCH; ++k) ok = ok && hipEventCreateWithFlags(&e->pre_ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { e->pre_stream = nullptr; pipe = false; }
+    }
+    if (!pipe) {
+        for (int done = 0; done < n;) {
+            const int r = std::min(n - done, rmax);
+            GG_TRY(prefetch_chunk(c, z_all, done, r, in, e->actsD, e->headD, e->c3));
+            done += r;
         }
-        GG_TRY(lin_fwd(c, z_all + (long)done * B * Lz, Lz, Gn.w + Gn.w1, Lz + E, nullptr, e->headD.a1, H, r * B, H, Lz));
-        GG_TRY(head_finish(c, Gn, cvec, e->headD.a1, e->headD.a2, e->Xpre + (long)done * B * G, G, r * B, r * B));
+        e->pre_n = n;
+        return 0;
+    }
+    GG_TRY(prefetch_chunk(c, z_all, 0, 1, in, e->actsD, e->headD, e->c3));
+    GG_CHECK_HIP(hipEventRecord(e->pre_fork, c.st));                        // after the shadow refresh and everything before it
+    GG_CHECK_HIP(hipStreamWaitEvent(e->pre_stream, e->pre_fork, 0));
+    Ctx cp{e, e->pre_stream};
+    for (int done = 1; done < n;) {
+        const int r = std::min(n - done, rmax);
+        GG_TRY(prefetch_chunk(cp, z_all, done, r, in, e->actsP, e->headP, e->c3P));
+        for (int k = done; k < done + r; ++k) {
+            GG_CHECK_HIP(hipEventRecord(e->pre_ev[k], e->pre_stream));
+            e->pre_wait[k] = true;
+        }
         done += r;
     }
     e->pre_n = n;
     return 0;
 }
-inline const float* next_prefetched(gg_engine* e, int B) {
+// next stored generator output (nullptr: none); the caller's stream waits for it if it is still being computed
+inline const float* next_prefetched(Ctx& c, int B) {
+    gg_engine* e = c.e;
     if (e->pre_next >= e->pre_n || e->pre_B != B) return nullptr;
-    return e->Xpre + (long)(e->pre_next++) * B * e->G;
+    const int k = e->pre_next++;
+    if (e->pre_wait[k]) {
+        if (hipStreamWaitEvent(c.st, e->pre_ev[k], 0) != hipSuccess) return nullptr;
+        e->pre_wait[k] = false;
+    }
+    return e->Xpre + (long)k * B * e->G;
 }
 
 int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
@@ -1188,6 +1250,7 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H, L = e->L;
+    GG_TRY(prefetch_drain(c));                     // passes of the frozen generator still in flight read its weights / shadows
     GG_TRY(refresh_shadows(c, Gn));
     GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
@@ -1256,6 +1319,12 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
 
 void gg_destroy(gg_engine* e) {
     if (!e) return;
+    if (e->pre_stream) {
+        (void)hipStreamSynchronize(e->pre_stream);
+        (void)hipEventDestroy(e->pre_fork);
+        for (int k = 0; k < GG_MAX_PREFETCH; ++k) (void)hipEventDestroy(e->pre_ev[k]);
+        (void)hipStreamDestroy(e->pre_stream);
+    }
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         (void)hipEventDestroy(e->ev_ready);
@@ -1324,7 +1393,7 @@ int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const 
     GG_REQUIRE(e && x_real && z && alpha && losses, "null argument");
     GG_TRY(check_cond(e, in));
     Ctx c{e, (hipStream_t)stream};
-    return critic_backward(c, x_real, z, alpha, in, losses, next_prefetched(e, in->B));
+    return critic_backward(c, x_real, z, alpha, in, losses, next_prefetched(c, in->B));
 }
 int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond* in, void* stream) {
     GG_REQUIRE(e && z_all && n >= 0, "bad argument");
@@ -1346,6 +1415,7 @@ int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* in, float
 int gg_generator_apply(gg_engine* e, float grad_scale, void* stream) {
     GG_REQUIRE(e, "null argument");
     Ctx c{e, (hipStream_t)stream};
+    if (prefetch_drain(c) != 0) return -1;
     e->pre_n = e->pre_next = 0;                       // the generator changes: outputs computed ahead are stale
     return apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, grad_scale);
 }
@@ -1360,7 +1430,7 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const fl
     const long zs = (long)in->B * e->L;
     if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in));
     for (int k = 0; k < n_critic; ++k) {
-        GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(e, in->B)));
+        GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(c, in->B)));
         GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
     }
     e->pre_n = e->pre_next = 0;
