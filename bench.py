@@ -179,7 +179,10 @@ def main():
     for i in range(args.warmup):
         last = i == args.warmup - 1
         if prof and last:
-            w.engine.profile(True)            # every GEMM class, untimed: the per-class table and the dominant class
+            # every GEMM class, untimed, with the engine's side streams serialised: ISOLATED kernel durations (the per-class
+            # table, the dominant class and its stand-alone roofline fraction)
+            w.engine.set_side_streams(False)
+            w.engine.profile(True)
         t1 = time.perf_counter()
         w.train(x, text, text_pad, patches, patch_pad)
         torch.cuda.synchronize(dev)
@@ -187,14 +190,18 @@ def main():
         if prof and last:
             rows_all = [r for r in w.engine.profile_collect() if r["launches"] > 0]
             w.engine.profile(False)
+            w.engine.set_side_streams(True)
     sync()
     if prof:
         # The timed region carries event pairs for the DOMINANT class only (live roofline over the timed steps): an event
         # pair around each of the ~600 GEMM-class launches of a step costs 3 ms per step on the host-fed stream.
         dom_cls = max(rows_all, key=lambda r: r["ms"])["name"] if rows_all else None
         w.engine.profile(True, [dom_cls] if dom_cls else None)
+    prof_steps = min(2, args.steps)               # timed steps that carry the event pairs (a host-side flag, no sync)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if prof and i == prof_steps:
+            w.engine.profile_pause()
         w.train(x, text, text_pad, patches, patch_pad)
     sync()
     dt = time.perf_counter() - t0
@@ -246,6 +253,13 @@ def main():
             frac_m, frac_h = tf / peak_tf, gbs / PEAK_HBM_GBS
             bound = "mfma" if frac_m >= frac_h else "hbm"
             traffic = pmc_traffic(dom["name"])
+            iso = None
+            for r in rows_all:
+                if r["name"] == dom["name"]:
+                    ig = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                    it = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                    iso = {"achieved": round(it if bound == "mfma" else ig, 2), "frac": round(max(it / peak_tf, ig / PEAK_HBM_GBS), 4),
+                           "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches": r["launches"]}
             out["roofline"] = {"kernel": dom["name"], "bound": bound,
                                "achieved": round(tf if bound == "mfma" else gbs, 2),
                                "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
@@ -255,7 +269,12 @@ def main():
                                                "profiles/r01_pmc_traffic.json; algorithmic bytes per launch = "
                                                + str(round(dom["bytes"] / dom["launches"] / 1e6, 1)) + " MB",
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
-                               "share_of_step": round(dom["ms"] / (dt * 1e3), 3),
+                               "share_of_step": round(dom["ms"] / (dt * 1e3 * prof_steps / args.steps), 3),
+                               "timed_steps_with_events": prof_steps,
+                               "note": "live over the timed region, where the kernel shares the chip with the parameter-gradient / "
+                                       "prefetch kernels of the engine's side streams; `isolated` is the same kernel class with the "
+                                       "streams serialised (untimed warm-up step)",
+                               "isolated": iso,
                                "all_gemm_classes_note": "one untimed warm-up step with event pairs on every class" if rows_all else
                                                         "timed region",
                                "all_gemm_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),

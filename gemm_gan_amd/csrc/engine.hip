@@ -1146,7 +1146,12 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
         GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_fwd(c, e->gp_dg1, H, D.w + D.w2, H, nullptr, e->gp_dg2, H, B, H, H));     // dg2 = du W2^T
-    KL(k_colsum_masked(e->gp_dg2, a2h, B, H, slope, D.g + D.w3, c.st));                    // dw3 += sum m2*dg2
+    {   // dw3 += sum m2*dg2 : on the side stream like the head's own dW3 (two streams must not add into one gradient)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(k_colsum_masked(e->gp_dg2, a2h, B, H, slope, D.g + D.w3, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     // ---- conditioning backward for the rows that carry gradient --------------------------------------
     if (R == 1) {
         KL(k_axpy(e->dc, e->dc + (long)B * E, 1.f, (long)B * E, c.st));
@@ -1455,6 +1460,11 @@ int gg_set_precision(gg_engine* e, int precision) {
     e->precision = precision;
     return 0;
 }
+int gg_set_side_streams(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->side_on = on != 0;
+    return 0;
+}
 int gg_set_prefetch(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->prefetch_on = on != 0;
@@ -1516,7 +1526,8 @@ int gg_set_optimizer_step(gg_engine* e, int role, int step) {
 int64_t gg_launch_count(const gg_engine* e) { return e ? e->launches : -1; }
 
 int gg_profile_enable(gg_engine* e, int on) {
-    GG_REQUIRE(e && on >= 0, "bad argument");
+    GG_REQUIRE(e, "null argument");
+    if (on < 0) { e->prof_on = false; return 0; }      // pause: no more event pairs, the records stay for gg_profile_collect
     e->prof_on = on != 0;
     e->prof_mask = on > 1 ? (unsigned)on >> 1 : 0xffffffffu;      // on = 1 | (class bit mask << 1) restricts the classes
     if (on) { e->prof_recs.clear(); e->prof_next = 0; }

@@ -141,6 +141,9 @@ class Engine:
         assert z_all.dim() == 3 and z_all.is_contiguous()
         L.check(self.lib.gg_generator_prefetch(self.h, _ptr(z_all), int(z_all.shape[0]), C.byref(cond), _stream()))
 
+    def set_side_streams(self, on):
+        L.check(self.lib.gg_set_side_streams(self.h, int(bool(on))))
+
     def set_prefetch(self, on):
         L.check(self.lib.gg_set_prefetch(self.h, int(bool(on))))
 
@@ -206,6 +209,11 @@ class Engine:
                 mask |= 1 << self.PROFILE_CLASSES.index(c)
             arg = 1 | (mask << 1)
         L.check(self.lib.gg_profile_enable(self.h, arg))
+
+    def profile_pause(self):
+        """Stop taking event pairs but keep the records (profile(False) followed by a collect would do the same; this
+        form does not clear them)."""
+        L.check(self.lib.gg_profile_enable(self.h, -1))
 
     def profile_collect(self):
         """[{name, launches, ms, flops, bytes}] per kernel class since profile(True)."""

@@ -131,6 +131,10 @@ int gg_generator_apply(gg_engine* e, float grad_scale, void* stream);
  * a data-parallel host loop (all-reduce between *_backward and *_apply) calls it once before its critic loop. */
 int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond* c, void* stream);
 int gg_set_prefetch(gg_engine* e, int on);
+/* Parameter gradients (leaves of the backward chain), the frozen critic's forward of the generator iteration and all but the
+ * first prefetched generator pass run on engine-owned streams beside the caller's; every entry point returns with the
+ * caller's stream waiting for them.  0 serialises everything on the caller's stream (isolated kernel timings). */
+int gg_set_side_streams(gg_engine* e, int on);
 
 /* ---- whole step on one GPU: WGAN_GP.train (R:463-477) -----------------------------------------------
  * z_all [n_critic+1, B, L], alpha_all [n_critic, B]; losses hold the LAST critic iteration's
@@ -170,6 +174,7 @@ int gg_debug_buffer_is_bf16(gg_engine* e, const char* name);   /* 1 if that buff
  * gg_profile_enable(e, 1) brackets every subsequent GEMM launch with an event pair taken from a pool;
  * gg_profile_enable(e, 1 | (mask << 1)) only the launches of the kernel classes whose bit is set in mask (bit i = row i of
  * the aggregate), so that a timed region can carry the events of ONE class without paying for all of them;
+ * gg_profile_enable(e, -1) stops taking events and keeps the records (0 stops and the next enable clears them);
  * gg_profile_collect synchronises the events and aggregates per kernel class (= kernel symbol:
  * "gemm_f32<A-layout,B-layout>") launches, total milliseconds, algorithmic FLOPs (2*M*N*K*batch) and
  * algorithmic bytes ((M*K + K*N + M*N)*4*batch).  gg_profile_read returns row i of the aggregate. */
