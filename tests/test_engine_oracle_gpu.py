@@ -399,3 +399,36 @@ def test_generator_prefetch_equals_sequential_passes():
         ck.check(f"critic parameters vs {other}", res["step_prefetch"]["wd"], res[other]["wd"])
         ck.check(f"generator parameters vs {other}", res["step_prefetch"]["wg"], res[other]["wg"])
     ck.done()
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+def test_side_streams_do_not_change_results(case):
+    """The engine's side streams (parameter-gradient leaves beside the data-gradient chain, the generator iteration's two
+    forward passes, the pipelined prefetch) only reorder independent work: a full train() must give the same parameters
+    as with everything serialised on the caller's stream (same seeds => same dropout masks; fp32 atomics reorder)."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], max(c["B"], 70), c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(7)
+    n = 3
+    z_all = torch.randn(n + 1, B, cfg.latent_dims, generator=g).cuda()
+    alpha_all = torch.rand(n, B, generator=g).cuda()
+    res = {}
+    for side in (True, False):
+        eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+        load_oracle_state(eng, tr)
+        eng.set_precision("bf16")
+        eng.set_side_streams(side)
+        eng.critic_backward(x, z_all[0].contiguous(), alpha_all[0].contiguous(), patches, patch_pad, text, text_pad)
+        gd = eng.flat[L.ROLE_CRITIC]["g"].clone()
+        eng.generator_backward(z_all[n].contiguous(), patches, patch_pad, text, text_pad)
+        gg = eng.flat[L.ROLE_GENERATOR]["g"].clone()
+        res[side] = dict(gd=gd, gg=gg, losses=eng.losses.clone())
+    ck = Checker(f"side streams on vs off {case}", 1e-4)
+    ck.check("critic gradient", res[True]["gd"], res[False]["gd"])
+    ck.check("generator gradient", res[True]["gg"], res[False]["gg"])
+    ck.check("losses", res[True]["losses"], res[False]["losses"])
+    ck.done()
