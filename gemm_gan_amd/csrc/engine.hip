@@ -1292,7 +1292,7 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
 extern "C" {
 
 const char* gg_last_error(void) { return gg::g_err.c_str(); }
-const char* gg_version(void) { return "gemm_gan_amd 0.1 (gfx950, f32-MFMA parity path)"; }
+const char* gg_version(void) { return "gemm_gan_amd 0.2 (gfx950: bf16-MFMA engine, f32-MFMA parity mode)"; }
 
 int gg_create(const gg_config* cfg, gg_engine** out) {
     GG_REQUIRE(cfg && out, "null argument");
