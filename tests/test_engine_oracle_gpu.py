@@ -19,6 +19,9 @@ CASES = {
                                            text_dims=512, patch_dims=1024, dropout=0.0), B=8, P=64, T=1),
     "leaky_T300": dict(cfg=PathConfig(n_genes=130, latent_dims=32, embedding_dims=32, hidden_dims=64, text_dims=24,
                                        patch_dims=16, dropout=0.0, negative_slope=0.2), B=6, P=9, T=300),
+    # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
+    "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
+                                          patch_dims=20, dropout=0.0), B=1, P=1, T=1),
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
