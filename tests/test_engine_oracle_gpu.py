@@ -435,3 +435,34 @@ def test_side_streams_do_not_change_results(case):
     ck.check("generator gradient", res[True]["gg"], res[False]["gg"])
     ck.check("losses", res[True]["losses"], res[False]["losses"])
     ck.done()
+
+
+@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample"])
+def test_bf16_mode_on_generic_shapes(case):
+    """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
+    one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    eng.set_precision("bf16")
+    B = x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    ck = Checker(f"bf16 mode vs fp32 oracle ({case})", 6e-2)
+    l = eng.losses.tolist()
+    ck.check("d_real,d_fake", np.array(l[:2]), np.array([r["d_real"].item(), r["d_fake"].item()]))
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    fa, fb = [], []
+    for n, ref in r["grads"].items():
+        if ref is None or n.endswith("in_proj_bias") or ref.abs().max() < 1e-12:
+            continue
+        fa.append(grads[n].reshape(-1).cpu())
+        fb.append(ref.reshape(-1))
+    total = _cos(torch.cat(fa), torch.cat(fb))
+    from gpu_util import diag
+    diag(f"   flat critic gradient cosine: {total:.5f}")
+    assert total >= 0.95, total
+    ck.done()
