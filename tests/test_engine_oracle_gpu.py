@@ -22,6 +22,9 @@ CASES = {
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
+    # S = 601 > the fused attention kernels' LDS-resident key range: the unfused (GEMM + softmax + GEMM) route
+    "long_S601": dict(cfg=PathConfig(n_genes=64, latent_dims=16, embedding_dims=64, hidden_dims=32, text_dims=24,
+                                      patch_dims=40, dropout=0.0), B=2, P=600, T=2),
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
@@ -437,7 +440,7 @@ def test_side_streams_do_not_change_results(case):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample"])
+@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""
