@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--text-dims", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--pad-frac", type=float, default=0.0,
+                    help="fraction of samples whose last P/4 patch tokens are padded (SURVEY 8d masking run: 0.25)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="bf16",
                     help="GEMM arithmetic: bf16 = bf16 MFMA operands, fp32 accumulate (BASELINE north_star; headline), "
                          "f32 = exact fp32-input MFMA (the 1e-3 parity mode)")
@@ -166,6 +168,8 @@ def main():
     patches = torch.randn(B, P, 1024, device=dev, generator=g)
     text = torch.randn(B, T, args.text_dims, device=dev, generator=g)
     patch_pad = torch.zeros(B, P, dtype=torch.bool, device=dev)
+    if args.pad_frac > 0:
+        patch_pad[: int(round(B * args.pad_frac)), P - P // 4:] = True
     text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
 
     def sync():
@@ -238,7 +242,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": {"workload": "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), "
                                       f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
-                                      f"n_critic=5, rms_prop, dropout {args.dropout}",
+                                      f"n_critic=5, rms_prop, dropout {args.dropout}"
+                                      + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count()},
                "finite": finite,
                "losses": {"d": losses_head[0], "g": losses_head[1]}}

@@ -690,9 +690,146 @@ __global__ __launch_bounds__(TPB) void sq_attn_fwd_k(const float* q, const float
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// Production width (E = 256, 4 heads of 64) with many keys (real text: T = 300): lane l of every wave owns features
+// 4l..4l+3 (head l >> 4), the four waves stride over the keys four rows at a time, so every K / V row is one coalesced
+// 1 KB access and is read exactly once per pass (the generic kernels above walk a row per lane).
+constexpr int SQ256_MAXS = 1024;
+template <int CTRL>
+__device__ __forceinline__ float dpp_k(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum_k(float v) {      // every lane of a 16-lane row ends with the row's sum
+    v += dpp_k<0xB1>(v);
+    v += dpp_k<0x4E>(v);
+    v += dpp_k<0x141>(v);
+    v += dpp_k<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float dot4_k(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+__global__ __launch_bounds__(TPB) void sq256_fwd_k(const float* __restrict__ q, const float* __restrict__ kv,
+                                                    const uint8_t* __restrict__ mask, int mask_B, float* __restrict__ probs,
+                                                    float* __restrict__ ctx, int S) {
+    constexpr int E = 256, NH = 4;
+    __shared__ float sc[NH][SQ256_MAXS];
+    __shared__ __attribute__((aligned(16))) float part[4][E];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 4;
+    const float* kvb = kv + (long)b * S * 2 * E + 4 * lane;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (long)b * E + 4 * lane) * 0.125f;       // 1/sqrt(64)
+    const uint8_t* mk = mask ? mask + (long)(b % mask_B) * S : nullptr;
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 kr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d = row16_sum_k(dot4_k(qv, kr[u]));
+            if ((lane & 15) == 0 && s0 + u < S) sc[h][s0 + u] = (mk && mk[s0 + u]) ? -INFINITY : d;
+        }
+    }
+    __syncthreads();
+    {   // softmax of head `wave`
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[wave][s]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float e = __expf(sc[wave][s] - m);
+            sc[wave][s] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int s = lane; s < S; s += 64) {
+            const float p = sc[wave][s] * inv;
+            sc[wave][s] = p;
+            probs[((long)b * NH + wave) * S + s] = p;
+        }
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 vr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E + E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < S) acc += sc[h][s0 + u] * vr[u];
+    }
+    *reinterpret_cast<f32x4*>(&part[wave][4 * lane]) = acc;
+    __syncthreads();
+    const int t = threadIdx.x;
+    ctx[(long)b * E + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+}
+
+__global__ __launch_bounds__(TPB) void sq256_bwd_k(const float* __restrict__ dctx, const float* __restrict__ q,
+                                                    const float* __restrict__ kv, const float* __restrict__ probs,
+                                                    float* __restrict__ dq, float* __restrict__ dkv, int S) {
+    constexpr int E = 256, NH = 4;
+    __shared__ float ds[NH][SQ256_MAXS];       // dctx_h . V_s
+    __shared__ float ps[NH][SQ256_MAXS];
+    __shared__ __attribute__((aligned(16))) float part[4][E];
+    __shared__ float red[4][NH];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 4;
+    const float* kvb = kv + (long)b * S * 2 * E + 4 * lane;
+    float* dkvb = dkv + (long)b * S * 2 * E + 4 * lane;
+    const f32x4 dcv = *reinterpret_cast<const f32x4*>(dctx + (long)b * E + 4 * lane);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (long)b * E + 4 * lane);
+    const float* ph = probs + ((long)b * NH + h) * S;
+    float dotp = 0.f;
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 vr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E + E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d = row16_sum_k(dot4_k(dcv, vr[u]));
+            if (s0 + u < S) {
+                const float p = ph[s0 + u];
+                dotp += d * p;
+                if ((lane & 15) == 0) {
+                    ds[h][s0 + u] = d;
+                    ps[h][s0 + u] = p;
+                }
+            }
+        }
+    }
+    if ((lane & 15) == 0) red[wave][h] = dotp;
+    __syncthreads();
+    const float dot = (red[0][h] + red[1][h]) + (red[2][h] + red[3][h]);        // sum_s p_s dp_s of this lane's head
+    f32x4 dqa = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 kr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u < S) {
+                const float p = ps[h][s0 + u];
+                const float g = p * (ds[h][s0 + u] - dot) * 0.125f;             // d(score_s)
+                *reinterpret_cast<f32x4*>(dkvb + (long)(s0 + u) * 2 * E) = g * qv;
+                *reinterpret_cast<f32x4*>(dkvb + (long)(s0 + u) * 2 * E + E) = p * dcv;
+                dqa += g * kr[u];
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&part[wave][4 * lane]) = dqa;
+    __syncthreads();
+    const int t = threadIdx.x;
+    dq[(long)b * E + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+}
+inline bool sq256_ok(const void* a, const void* b_, const void* c_, const void* d, int S, int E, int nh) {
+    return E == 256 && nh == 4 && S >= 4 && S <= SQ256_MAXS &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b_) | reinterpret_cast<uintptr_t>(c_) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
 int k_sq_attn_fwd(const float* q, const float* kv, const uint8_t* mask, int mask_B, float* probs, float* ctx, int B,
                   int S, int E, int nh, hipStream_t st) {
     GG_REQUIRE(S <= SQ_MAXS, "single-query attention: too many keys");
+    if (sq256_ok(q, kv, ctx, ctx, S, E, nh)) {
+        sq256_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S);
+        GG_LAUNCH_CHECK();
+    }
     sq_attn_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S, E, nh);
     GG_LAUNCH_CHECK();
 }
@@ -741,6 +878,10 @@ __global__ __launch_bounds__(TPB) void sq_attn_bwd_k(const float* dctx, const fl
 int k_sq_attn_bwd(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv, int B,
                   int S, int E, int nh, hipStream_t st) {
     GG_REQUIRE(S <= SQ_MAXS, "single-query attention: too many keys");
+    if (sq256_ok(dctx, q, kv, dkv, S, E, nh)) {
+        sq256_bwd_k<<<B, TPB, 0, st>>>(dctx, q, kv, probs, dq, dkv, S);
+        GG_LAUNCH_CHECK();
+    }
     sq_attn_bwd_k<<<B, TPB, 0, st>>>(dctx, q, kv, probs, dq, dkv, S, E, nh);
     GG_LAUNCH_CHECK();
 }

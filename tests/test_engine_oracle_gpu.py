@@ -19,6 +19,10 @@ CASES = {
                                            text_dims=512, patch_dims=1024, dropout=0.0), B=8, P=64, T=1),
     "leaky_T300": dict(cfg=PathConfig(n_genes=130, latent_dims=32, embedding_dims=32, hidden_dims=64, text_dims=24,
                                        patch_dims=16, dropout=0.0, negative_slope=0.2), B=6, P=9, T=300),
+    # production width with many text tokens (real text has T = 300): the coalesced single-query attention kernels;
+    # 77 = four 16-key rounds + a ragged 13
+    "text_T77_E256": dict(cfg=PathConfig(n_genes=120, latent_dims=32, embedding_dims=256, hidden_dims=64, text_dims=48,
+                                          patch_dims=40, dropout=0.0), B=5, P=20, T=77),
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
@@ -440,7 +444,7 @@ def test_side_streams_do_not_change_results(case):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601"])
+@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""
