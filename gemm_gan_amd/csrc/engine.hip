@@ -80,6 +80,7 @@ struct CondActs {
     float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar, *t2i_qt;
     bool sqx = false;          // projection-free single-query T2I attention, generic kernel
     bool share0 = false;       // dropout replicas share the layer-0 input x0 and its QKV projection (no replicated copy)
+    bool i2t_shared = false;   // I2T keys / values (projected text tokens) exist once for all replicas (many text tokens)
     bool sqx2 = false;         // ... streaming kernels with the per-head projections hoisted into batched GEMMs
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
@@ -676,8 +677,18 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
     // I2T: query = that vector, keys = values = encoded text tokens (R:220)
     GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
-    GG_TRY(lin_fwd(c, tok, E, w + n.i2t.inw + (long)E * E, E, w + n.i2t.inb + E, a.i2t_kv, 2 * E, (int)(RB * T), 2 * E, E));
-    KL(k_sq_attn_fwd(a.i2t_q, a.i2t_kv, in->text_pad, B, a.i2t_P, a.i2t_ctx, (int)RB, T, E, nh, c.st));
+    // the text tokens carry no dropout: their K / V projection is the same for every replica
+    static const bool no_i2t_share = getenv("GG_NO_I2T_SHARE") != nullptr;
+    a.i2t_shared = !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
+    if (a.i2t_shared) {
+        TlinP t;
+        t.X = a.tok; t.ldx = E; t.M = (long)B * T; t.W = WB(n, n.i2t.inw + (long)E * E); t.ldw = E; t.bias = w + n.i2t.inb + E;
+        t.Y = a.i2t_kv; t.ldy = 2 * E; t.N = 2 * E; t.K = E;
+        TLIN_OR(t, GG_TRY(lin_fwd(c, a.tok, E, w + n.i2t.inw + (long)E * E, E, w + n.i2t.inb + E, a.i2t_kv, 2 * E, B * T, 2 * E, E)));
+    } else {
+        GG_TRY(lin_fwd(c, tok, E, w + n.i2t.inw + (long)E * E, E, w + n.i2t.inb + E, a.i2t_kv, 2 * E, (int)(RB * T), 2 * E, E));
+    }
+    KL(k_sq_attn_fwd(a.i2t_q, a.i2t_kv, in->text_pad, B, a.i2t_P, a.i2t_ctx, (int)RB, T, E, nh, c.st, a.i2t_shared ? B : 0));
     GG_TRY(lin_fwd(c, a.i2t_ctx, E, w + n.i2t.ow, E, w + n.i2t.ob, a.i2t_out, E, (int)RB, E, E));
     KL(k_copy(a.c, a.t2i_out, RB * E, c.st));
     KL(k_axpy(a.c, a.i2t_out, 1.f, RB * E, c.st));
@@ -745,7 +756,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_tmpE, E, (int)RB, E, E));
-    KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
+    const bool i2t_sh = a.i2t_shared && sq_attn_shared_ok(T, E, nh, Rb);
+    GG_REQUIRE(i2t_sh || !a.i2t_shared, "shared I2T keys: backward replica count not supported");
+    if (i2t_sh) KL(k_sq_attn_bwd_shared(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, B, Rb, T, E, nh, c.st));
+    else KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;
         const bool fk = side_begin(c, cs);
@@ -758,11 +772,21 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;
         const bool fk = side_begin(c, cs);
-        GG_TRY(lin_bwd_weight(cs, e->s_dkv2, 2 * E, tok, E, g + n.i2t.inw + (long)E * E, E, (int)(RB * T), 2 * E, E));
-        GG_TRY(k_colsum(e->s_dkv2, RB * T, 2 * E, 2 * E, g + n.i2t.inb + E, cs.st)); e->launches++;
+        // shared keys: s_dkv2 is already summed over the replicas, [B*T, 2E] against the un-replicated tokens
+        const long Mkv = i2t_sh ? (long)B * T : RB * T;
+        GG_TRY(lin_bwd_weight(cs, e->s_dkv2, 2 * E, i2t_sh ? a.tok : tok, E, g + n.i2t.inw + (long)E * E, E, (int)Mkv, 2 * E, E));
+        GG_TRY(k_colsum(e->s_dkv2, Mkv, 2 * E, 2 * E, g + n.i2t.inb + E, cs.st)); e->launches++;
         GG_TRY(side_end(c, fk, 3));
     }
-    GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
+    if (i2t_sh) {   // the token gradient of all replicas lands in replica 0's slab; the others start from zero (T2I adds its rows)
+        TlinP t;
+        t.X = e->s_dkv2; t.ldx = 2 * E; t.M = (long)B * T; t.W = WTB(n, n.i2t.inw + E); t.ldw = 3 * E;     // columns E..3E of in_proj^T
+        t.Y = e->s_dtokrep; t.ldy = E; t.N = E; t.K = 2 * E;
+        TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, B * T, 2 * E, E)));
+        if (Rb > 1) KL(k_fill(e->s_dtokrep + (long)B * T * E, (long)(Rb - 1) * B * T * E, 0.f, c.st));
+    } else {
+        GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
+    }
     // ---- T2I backward ---------------------------------------------------------------------------------
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;

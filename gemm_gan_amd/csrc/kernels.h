@@ -71,11 +71,17 @@ int k_mask_times_vec(float* out, const float* ref, const float* w, long rows, in
 // single-query multi-head attention (query length 1): q [B,E] (projected), kv [B,S,2E] (K|V projected)
 // mask [B,S] bytes (nonzero = ignore).  probs [B,nh,S], ctx [B,E].
 // mask row of sample b is b % mask_B (replica-stacked batches share the mask of the original batch)
+// kv_B > 0: the keys / values of sample b are block b % kv_B (replicas share one projection; needs sq_attn_shared_ok)
 int k_sq_attn_fwd(const float* q, const float* kv, const uint8_t* mask, int mask_B, float* probs, float* ctx,
-                  int B, int S, int E, int nh, hipStream_t st);
+                  int B, int S, int E, int nh, hipStream_t st, int kv_B = 0);
 // dctx [B,E] -> dq [B,E] (overwritten), dkv [B,S,2E] (overwritten)
 int k_sq_attn_bwd(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv,
                   int B, int S, int E, int nh, hipStream_t st);
+// R replica-stacked queries (row r*B + b) over ONE key/value projection kv [B,S,2E]: dq [R*B,E] per replica, dkv [B,S,2E] is
+// the SUM over the replicas (what the projection's weight / data gradients need: they are linear in it)
+bool sq_attn_shared_ok(int S, int E, int nh, int R);
+int k_sq_attn_bwd_shared(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv,
+                         int B, int R, int S, int E, int nh, hipStream_t st);
 
 // out[i] = sum_{r<R} in[r*n + i]   (fold replica-stacked gradients)
 int k_fold(float* out, const float* in, long n, int R, hipStream_t st);

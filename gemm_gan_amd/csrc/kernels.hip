@@ -710,12 +710,12 @@ __device__ __forceinline__ float dot4_k(f32x4 a, f32x4 b) { return a[0] * b[0] +
 
 __global__ __launch_bounds__(TPB) void sq256_fwd_k(const float* __restrict__ q, const float* __restrict__ kv,
                                                     const uint8_t* __restrict__ mask, int mask_B, float* __restrict__ probs,
-                                                    float* __restrict__ ctx, int S) {
+                                                    float* __restrict__ ctx, int S, int kv_B) {
     constexpr int E = 256, NH = 4;
     __shared__ float sc[NH][SQ256_MAXS];
     __shared__ __attribute__((aligned(16))) float part[4][E];
     const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 4;
-    const float* kvb = kv + (long)b * S * 2 * E + 4 * lane;
+    const float* kvb = kv + (long)(b % kv_B) * S * 2 * E + 4 * lane;
     const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (long)b * E + 4 * lane) * 0.125f;       // 1/sqrt(64)
     const uint8_t* mk = mask ? mask + (long)(b % mask_B) * S : nullptr;
     for (int s0 = 4 * wave; s0 < S; s0 += 16) {
@@ -824,12 +824,13 @@ inline bool sq256_ok(const void* a, const void* b_, const void* c_, const void* 
            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b_) | reinterpret_cast<uintptr_t>(c_) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 int k_sq_attn_fwd(const float* q, const float* kv, const uint8_t* mask, int mask_B, float* probs, float* ctx, int B,
-                  int S, int E, int nh, hipStream_t st) {
+                  int S, int E, int nh, hipStream_t st, int kv_B) {
     GG_REQUIRE(S <= SQ_MAXS, "single-query attention: too many keys");
     if (sq256_ok(q, kv, ctx, ctx, S, E, nh)) {
-        sq256_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S);
+        sq256_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S, kv_B > 0 ? kv_B : B);
         GG_LAUNCH_CHECK();
     }
+    GG_REQUIRE(kv_B <= 0 || kv_B == B, "shared keys / values need the E = 256 kernels (sq_attn_shared_ok)");
     sq_attn_fwd_k<<<B, TPB, 0, st>>>(q, kv, mask, mask_B > 0 ? mask_B : B, probs, ctx, S, E, nh);
     GG_LAUNCH_CHECK();
 }
@@ -874,6 +875,104 @@ __global__ __launch_bounds__(TPB) void sq_attn_bwd_k(const float* dctx, const fl
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// R replicas of sample b (rows r*B + b of dctx / q / probs / dq) attend to the SAME projected keys / values: one workgroup
+// per sample reads every K / V row once and writes the replica-summed dK / dV row once.
+template <int R>
+__global__ __launch_bounds__(TPB) void sq256_bwd_shared_k(const float* __restrict__ dctx, const float* __restrict__ q,
+                                                           const float* __restrict__ kv, const float* __restrict__ probs,
+                                                           float* __restrict__ dq, float* __restrict__ dkv, int B, int S) {
+    constexpr int E = 256, NH = 4;
+    extern __shared__ __attribute__((aligned(16))) float sq_dyn[];
+    float* const ds = sq_dyn;                      // [R][NH][S]  dctx_h . V_s
+    float* const ps = sq_dyn + R * NH * S;         // [R][NH][S]  probabilities
+    __shared__ __attribute__((aligned(16))) float part[4][E];
+    __shared__ float red[4][R][NH];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 4;
+    const float* kvb = kv + (long)b * S * 2 * E + 4 * lane;
+    float* dkvb = dkv + (long)b * S * 2 * E + 4 * lane;
+    f32x4 dcv[R], qv[R];
+    float dotp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        dcv[r] = *reinterpret_cast<const f32x4*>(dctx + ((long)r * B + b) * E + 4 * lane);
+        qv[r] = *reinterpret_cast<const f32x4*>(q + ((long)r * B + b) * E + 4 * lane);
+        dotp[r] = 0.f;
+    }
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 vr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E + E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d = row16_sum_k(dot4_k(dcv[r], vr[u]));
+                if (s0 + u < S) {
+                    const float p = probs[(((long)r * B + b) * NH + h) * S + s0 + u];
+                    dotp[r] += d * p;
+                    if ((lane & 15) == 0) {
+                        ds[(r * NH + h) * S + s0 + u] = d;
+                        ps[(r * NH + h) * S + s0 + u] = p;
+                    }
+                }
+            }
+        }
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[wave][r][h] = dotp[r];
+    }
+    __syncthreads();
+    float dot[R];
+    f32x4 dqa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        dot[r] = (red[0][r][h] + red[1][r][h]) + (red[2][r][h] + red[3][r][h]);
+        dqa[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int s0 = 4 * wave; s0 < S; s0 += 16) {
+        f32x4 kr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kr[u] = *reinterpret_cast<const f32x4*>(kvb + (long)min(s0 + u, S - 1) * 2 * E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u < S) {
+                f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float p = ps[(r * NH + h) * S + s0 + u];
+                    const float g = p * (ds[(r * NH + h) * S + s0 + u] - dot[r]) * 0.125f;
+                    dk += g * qv[r];
+                    dv += p * dcv[r];
+                    dqa[r] += g * kr[u];
+                }
+                *reinterpret_cast<f32x4*>(dkvb + (long)(s0 + u) * 2 * E) = dk;
+                *reinterpret_cast<f32x4*>(dkvb + (long)(s0 + u) * 2 * E + E) = dv;
+            }
+        }
+    }
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r > 0) __syncthreads();
+        *reinterpret_cast<f32x4*>(&part[wave][4 * lane]) = dqa[r];
+        __syncthreads();
+        dq[((long)r * B + b) * E + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    }
+}
+bool sq_attn_shared_ok(int S, int E, int nh, int R) {
+    return E == 256 && nh == 4 && S >= 4 && S <= SQ256_MAXS && R >= 1 && R <= 3 && (size_t)2 * R * 4 * S * sizeof(float) <= 48 * 1024;
+}
+int k_sq_attn_bwd_shared(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv, int B,
+                         int R, int S, int E, int nh, hipStream_t st) {
+    GG_REQUIRE(sq_attn_shared_ok(S, E, nh, R) && sq256_ok(dctx, q, kv, dkv, S, E, nh), "shared-key single-query attention: unsupported shape");
+    const size_t smem = (size_t)2 * R * 4 * S * sizeof(float);
+    if (R == 1) sq256_bwd_shared_k<1><<<B, TPB, smem, st>>>(dctx, q, kv, probs, dq, dkv, B, S);
+    else if (R == 2) sq256_bwd_shared_k<2><<<B, TPB, smem, st>>>(dctx, q, kv, probs, dq, dkv, B, S);
+    else sq256_bwd_shared_k<3><<<B, TPB, smem, st>>>(dctx, q, kv, probs, dq, dkv, B, S);
+    GG_LAUNCH_CHECK();
 }
 int k_sq_attn_bwd(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv, int B,
                   int S, int E, int nh, hipStream_t st) {
