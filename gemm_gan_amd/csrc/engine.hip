@@ -156,7 +156,7 @@ struct gg_engine {
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
-    float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
+    float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
     // live profiling
     bool prof_on = false;
@@ -311,6 +311,7 @@ size_t carve(gg_engine* e, void* base) {
     e->s_dkv2 = a.take<float>(Rb * T * 2 * E);
     e->s_dtokrep = a.take<float>(Rb * T * E);
     e->s_dtok = a.take<float>(B * T * E);
+    e->s_dtok0 = a.take<float>(Rb * E);
     e->s_dx0 = a.take<float>(B * S * E);
     e->s_demb = a.take<float>(B * P * E);
     e->s_mod = a.take<float>(B * P * Dp);
@@ -531,7 +532,14 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     GG_TRY(lin_fwd(c, in->text, (long)T * Dt, w + n.film_w, Dt, w + n.film_b, a.gbpre, 2 * Dp, B, 2 * Dp, Dt));
     KL(k_film_act_fwd(a.gbpre, a.gb, B, Dp, c.st));
     // text encoder
-    GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt));
+    if ((long)B * T >= 4096) {      // many text tokens: the token-on-lane kernel (a handful of rows stays with the small-GEMM path)
+        TlinP t;
+        t.X = in->text; t.ldx = Dt; t.M = (long)B * T; t.W = WB(n, n.te_w); t.ldw = Dt; t.bias = w + n.te_b;
+        t.Y = a.tok; t.ldy = E; t.N = E; t.K = Dt;
+        TLIN_OR(t, GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt)));
+    } else {
+        GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt));
+    }
     // patch encoder with FiLM fused on the A operand; rows land behind the CLS row of each sample
     {
         TlinP t;
@@ -556,6 +564,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // The replicas differ only by their dropout draws, and nothing is dropped before the first attention: the layer-0
     // input x0 and its QKV projection are the same for all of them.  With the fused kernels (row / sample indices taken
     // modulo the un-replicated size) neither the R-fold copy of x0 nor R-1 of the R projections exist.
+    // the text tokens carry no dropout: their I2T K / V projection is the same for every replica
+    static const bool no_i2t_share = getenv("GG_NO_I2T_SHARE") != nullptr;
+    a.i2t_shared = !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
     const bool share0 = R > 1 && bst && e->wgrad_on && (long)B * S >= 4096;      // (the weight-gradient kernel must engage)
     a.share0 = share0;
     const float* x_in = a.x0;
@@ -565,7 +576,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             KL(k_copy_rows_bcast(a.xrep, a.x0, RB * S, (long)B * S, E, c.st));
             x_in = a.xrep;
         }
-        KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
+        // shared I2T keys: only the text CLS row (token 0) of every replica is read from the replicated layout
+        if (a.i2t_shared) KL(k_copy_rows_strided_bcast(a.tokrep, (long)T * E, a.tok, (long)T * E, RB, B, E, c.st));
+        else KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
         tok = a.tokrep;
     }
     for (int l = 0; l < e->nl; ++l) {
@@ -677,9 +690,6 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
     // I2T: query = that vector, keys = values = encoded text tokens (R:220)
     GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
-    // the text tokens carry no dropout: their K / V projection is the same for every replica
-    static const bool no_i2t_share = getenv("GG_NO_I2T_SHARE") != nullptr;
-    a.i2t_shared = !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
     if (a.i2t_shared) {
         TlinP t;
         t.X = a.tok; t.ldx = E; t.M = (long)B * T; t.W = WB(n, n.i2t.inw + (long)E * E); t.ldw = E; t.bias = w + n.i2t.inb + E;
@@ -778,12 +788,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(k_colsum(e->s_dkv2, Mkv, 2 * E, 2 * E, g + n.i2t.inb + E, cs.st)); e->launches++;
         GG_TRY(side_end(c, fk, 3));
     }
-    if (i2t_sh) {   // the token gradient of all replicas lands in replica 0's slab; the others start from zero (T2I adds its rows)
+    if (i2t_sh) {   // the token gradient of all replicas, [B*T, E]; the T2I query rows are added at the fold below
         TlinP t;
         t.X = e->s_dkv2; t.ldx = 2 * E; t.M = (long)B * T; t.W = WTB(n, n.i2t.inw + E); t.ldw = 3 * E;     // columns E..3E of in_proj^T
         t.Y = e->s_dtokrep; t.ldy = E; t.N = E; t.K = 2 * E;
         TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, B * T, 2 * E, E)));
-        if (Rb > 1) KL(k_fill(e->s_dtokrep + (long)B * T * E, (long)(Rb - 1) * B * T * E, 0.f, c.st));
     } else {
         GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
     }
@@ -832,13 +841,15 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             GG_TRY(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, cs.st)); e->launches++;
             GG_TRY(side_end(c, fk, 3));
         }
-        GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
+        else GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
     } else {
         GG_TRY(side_wait(c, 3));                  // s_dq is rewritten: the I2T in-projection gradient on the side stream reads it
         KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
         GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
         KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
-        GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
+        else GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
         GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
         KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
         {   // denc = dkv Wkv : reduction over the 2E projected features, W^T = columns E..3E of in_proj^T
@@ -976,10 +987,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const float* dtok = e->s_dtokrep;
     if (Rb > 1) {
         KL(k_fold(e->s_dx0, dx, (long)B * S * E, Rb, c.st));
-        KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
+        if (!i2t_sh) KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
         dx0 = e->s_dx0;
-        dtok = e->s_dtok;
+        if (!i2t_sh) dtok = e->s_dtok;
     }
+    if (i2t_sh) KL(k_fold_rows_add(e->s_dtokrep, (long)T * E, e->s_dtok0, B, Rb, E, c.st));      // + the T2I query rows (token 0)
     KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
     KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
     if (wgrad_film_ok(e, e->s_demb, E, in->patches, Dp, B * P, E, Dp, P)) {

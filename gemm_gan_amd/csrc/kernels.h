@@ -83,6 +83,10 @@ bool sq_attn_shared_ok(int S, int E, int nh, int R);
 int k_sq_attn_bwd_shared(const float* dctx, const float* q, const float* kv, const float* probs, float* dq, float* dkv,
                          int B, int R, int S, int E, int nh, hipStream_t st);
 
+// dst[r*ldd + c] = src[(r % src_rows)*lds + c], c < cols   (replicate selected rows of a strided matrix)
+int k_copy_rows_strided_bcast(float* dst, long ldd, const float* src, long lds, long rows, long src_rows, int cols, hipStream_t st);
+// dst[b*ldd + c] += sum_{r<R} src[(r*B + b)*cols + c]   (fold replica-stacked rows into a strided destination)
+int k_fold_rows_add(float* dst, long ldd, const float* src, long B, int R, int cols, hipStream_t st);
 // out[i] = sum_{r<R} in[r*n + i]   (fold replica-stacked gradients)
 int k_fold(float* out, const float* in, long n, int R, hipStream_t st);
 // out[(b*P+p), :] = seq[b, 1+p, :]   (drop the CLS row: [B,P+1,E] -> [B*P,E])

@@ -87,6 +87,32 @@ int k_copy_rows_bcast(float* dst, const float* src, long rows, long src_rows, in
     copy_rows_bcast_k<<<nblocks(rows * cols, TPB, 8192), TPB, 0, st>>>(dst, src, rows, src_rows, cols);
     GG_LAUNCH_CHECK();
 }
+__global__ void copy_rows_strided_bcast_k(float* dst, long ldd, const float* src, long lds, long rows, long src_rows, int cols) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[(r % src_rows) * lds + c];
+    }
+}
+int k_copy_rows_strided_bcast(float* dst, long ldd, const float* src, long lds, long rows, long src_rows, int cols, hipStream_t st) {
+    copy_rows_strided_bcast_k<<<nblocks(rows * cols, TPB, 8192), TPB, 0, st>>>(dst, ldd, src, lds, rows, src_rows, cols);
+    GG_LAUNCH_CHECK();
+}
+__global__ void fold_rows_add_k(float* dst, long ldd, const float* src, long B, int R, int cols) {
+    const long n = B * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / cols;
+        const int c = (int)(i - b * cols);
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += src[((long)r * B + b) * cols + c];
+        dst[b * ldd + c] += s;
+    }
+}
+int k_fold_rows_add(float* dst, long ldd, const float* src, long B, int R, int cols, hipStream_t st) {
+    fold_rows_add_k<<<nblocks(B * cols, TPB, 8192), TPB, 0, st>>>(dst, ldd, src, B, R, cols);
+    GG_LAUNCH_CHECK();
+}
 __global__ void axpy_k(float* y, const float* x, float a, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
