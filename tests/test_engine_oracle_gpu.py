@@ -78,6 +78,45 @@ def test_critic_and_generator_iteration_vs_autograd(case):
     ck.done()
 
 
+@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256"])
+def test_replica_stacked_passes_vs_autograd(case):
+    """With dropout on, the three critic passes of an iteration run as replicas stacked on the batch axis (two of them
+    carry gradient; shared layer inputs, shared text keys, replica-summed gradients).  A drop probability of 1e-7 keeps
+    every element (threshold round(p * 65536) = 0, scale 1 + 1e-7), so that route must reproduce the dropout-free
+    autograd reference within the parity tolerance."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    set_dropout(tr.gen, 0.0)
+    set_dropout(tr.disc, 0.0)
+    x, text, text_pad, patches, patch_pad = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=1e-7)
+    load_oracle_state(eng, tr)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    ck = Checker(f"replica-stacked critic/gen iteration {case}", TOL)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    l = eng.losses.tolist()
+    ck.check("d_real,d_fake,gp", np.array(l[:3]), np.array([r["d_real"].item(), r["d_fake"].item(), r["gp"].item()]))
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    for n, ref in r["grads"].items():
+        if ref is not None:
+            ck.check("dD " + n, grads[n], ref)
+    rg = tr.generator_iteration(z, cond, apply=False)
+    eng.generator_backward(zg, pg, ppg, tg, tpg)
+    ck.check("g_loss", np.array([eng.losses.tolist()[3]]), np.array([rg["g_loss"].item()]))
+    grads = eng.state(L.ROLE_GENERATOR, "g")
+    for n, ref in rg["grads"].items():
+        if ref is not None:
+            ck.check("dG " + n, grads[n], ref)
+    ck.done()
+
+
 def test_full_size_properties_cfg3():
     """BASELINE cfg3 (B=256, G=5000, P=256, Dp=1024, T=1, Dt=512): size-independent properties.
     (1) critic score is independent of the batch composition (row b of a half batch == row b of the
