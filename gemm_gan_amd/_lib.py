@@ -18,6 +18,7 @@ OPT_KINDS = {"rms_prop": 0, "adam": 1, "adamw": 2}
 LOSS_D_REAL, LOSS_D_FAKE, LOSS_GP, LOSS_G, N_LOSSES = 0, 1, 2, 3, 8
 LAY_KC, LAY_KS = 0, 1
 PRECISIONS = {"f32": 0, "bf16": 1}
+VARIANTS = {"xattn_film": 0, "film": 1}      # GG_VARIANT_* (include/gemmgan.h)
 
 
 class GGConfig(C.Structure):
@@ -27,7 +28,7 @@ class GGConfig(C.Structure):
                 ("dropout", C.c_float), ("lr_d", C.c_float), ("lr_g", C.c_float), ("optimizer", C.c_int32),
                 ("gp_weight", C.c_float), ("clip_d", C.c_float), ("clip_g", C.c_float),
                 ("max_batch", C.c_int32), ("max_patches", C.c_int32), ("max_text_tokens", C.c_int32),
-                ("seed", C.c_uint64), ("precision", C.c_int32)]
+                ("seed", C.c_uint64), ("precision", C.c_int32), ("variant", C.c_int32)]
 
 
 class GGCond(C.Structure):

@@ -63,6 +63,14 @@ struct Net {
         ps.push_back(p);
         return p.off;
     }
+    // slot that exists in the flat buffers but is no parameter of this variant (a bias of a bias-free layer, the text
+    // cross-attention of a FiLM-only model): zero, invisible to the state dict, behind `live` so no optimiser touches it
+    long add_ghost(int d0, int d1 = 0) {
+        const long off = total;
+        total += ((long)d0 * (d1 ? d1 : 1) + 7) / 8 * 8;
+        return off;
+    }
+    long live = 0;      // the optimiser, the gradient norm and the state dict cover [0, live)
 };
 
 struct LayerActs {
@@ -115,6 +123,8 @@ struct gg_engine {
     Net net[2];
     float dropout = 0.f;
     int precision = GG_PREC_F32;
+    bool xattn = true;         // text<->image cross attention (conditional_gan_cross_attention_with_film.py); false: CLS row (conditional_gan_film.py)
+    bool enc_bias = true;      // encoder layers with biases (bias=False in conditional_gan_film.py:115)
     uint64_t seed = 0;
     uint32_t call_counter = 0;
     int64_t launches = 0;
@@ -181,28 +191,32 @@ void build_net(gg_engine* e, int role) {
     n.V = role == GG_ROLE_GENERATOR ? e->L : e->G;
     n.OUT = role == GG_ROLE_GENERATOR ? e->G : 1;
     const std::string mlp = role == GG_ROLE_GENERATOR ? "generator" : "discriminator";
+    // visible parameters first, ghosts (see Net::add_ghost) behind them
+    const bool xa = e->xattn, eb = e->enc_bias;
     n.cls = n.add("patches_cls_token", 1, 1, E);
     n.film_w = n.add("film_generator.weight", 2 * Dp, Dt);
     n.film_b = n.add("film_generator.bias", 2 * Dp);
-    n.te_w = n.add("text_encoder.weight", E, Dt);
-    n.te_b = n.add("text_encoder.bias", E);
+    if (xa) {
+        n.te_w = n.add("text_encoder.weight", E, Dt);
+        n.te_b = n.add("text_encoder.bias", E);
+    }
     n.pe_w = n.add("patches_encoder.weight", E, Dp);
     n.pe_b = n.add("patches_encoder.bias", E);
     for (int l = 0; l < e->nl; ++l) {
         const std::string p = "patches_transformer.layers." + std::to_string(l) + ".";
         LayerP& L = n.layer[l];
         L.sa.inw = n.add(p + "self_attn.in_proj_weight", 3 * E, E);
-        L.sa.inb = n.add(p + "self_attn.in_proj_bias", 3 * E);
+        if (eb) L.sa.inb = n.add(p + "self_attn.in_proj_bias", 3 * E);
         L.sa.ow = n.add(p + "self_attn.out_proj.weight", E, E);
-        L.sa.ob = n.add(p + "self_attn.out_proj.bias", E);
+        if (eb) L.sa.ob = n.add(p + "self_attn.out_proj.bias", E);
         L.l1w = n.add(p + "linear1.weight", F, E);
-        L.l1b = n.add(p + "linear1.bias", F);
+        if (eb) L.l1b = n.add(p + "linear1.bias", F);
         L.l2w = n.add(p + "linear2.weight", E, F);
-        L.l2b = n.add(p + "linear2.bias", E);
+        if (eb) L.l2b = n.add(p + "linear2.bias", E);
         L.n1w = n.add(p + "norm1.weight", E);
-        L.n1b = n.add(p + "norm1.bias", E);
+        if (eb) L.n1b = n.add(p + "norm1.bias", E);
         L.n2w = n.add(p + "norm2.weight", E);
-        L.n2b = n.add(p + "norm2.bias", E);
+        if (eb) L.n2b = n.add(p + "norm2.bias", E);
     }
     auto attn = [&](const std::string& p, AttnP& a) {
         a.inw = n.add(p + "in_proj_weight", 3 * E, E);
@@ -210,14 +224,29 @@ void build_net(gg_engine* e, int role) {
         a.ow = n.add(p + "out_proj.weight", E, E);
         a.ob = n.add(p + "out_proj.bias", E);
     };
-    attn("patch2text_attention.", n.t2i);
-    attn("text2patch_attention.", n.i2t);
+    if (xa) {
+        attn("patch2text_attention.", n.t2i);
+        attn("text2patch_attention.", n.i2t);
+    }
     n.w1 = n.add(mlp + ".0.0.weight", H, n.V + E);
     n.b1 = n.add(mlp + ".0.0.bias", H);
     n.w2 = n.add(mlp + ".1.0.weight", H, H);
     n.b2 = n.add(mlp + ".1.0.bias", H);
     n.w3 = n.add("final_layer.weight", n.OUT, H);
     n.b3 = n.add("final_layer.bias", n.OUT);
+    n.live = n.total;
+    if (!eb) {
+        for (int l = 0; l < e->nl; ++l) {
+            LayerP& L = n.layer[l];
+            L.sa.inb = n.add_ghost(3 * E); L.sa.ob = n.add_ghost(E); L.l1b = n.add_ghost(F); L.l2b = n.add_ghost(E);
+            L.n1b = n.add_ghost(E); L.n2b = n.add_ghost(E);
+        }
+    }
+    if (!xa) {      // never read: the offsets only have to be valid
+        n.te_w = n.te_b = n.add_ghost(8);
+        n.t2i.inw = n.t2i.inb = n.t2i.ow = n.t2i.ob = n.te_w;
+        n.i2t = n.t2i;
+    }
     // 2-D weights of the conditioning stack get bf16 shadows (the MLP head products are short-M and stay generic)
     for (const ParamInfo& pi : n.ps) {
         if (pi.ndim != 2) continue;
@@ -532,7 +561,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     GG_TRY(lin_fwd(c, in->text, (long)T * Dt, w + n.film_w, Dt, w + n.film_b, a.gbpre, 2 * Dp, B, 2 * Dp, Dt));
     KL(k_film_act_fwd(a.gbpre, a.gb, B, Dp, c.st));
     // text encoder
-    if ((long)B * T >= 4096) {      // many text tokens: the token-on-lane kernel (a handful of rows stays with the small-GEMM path)
+    if (!e->xattn) {
+        // FiLM-only variant: no token encoder, no cross attention (conditional_gan_film.py:130-152)
+    } else if ((long)B * T >= 4096) {      // many text tokens: the token-on-lane kernel (a handful of rows stays with the small-GEMM path)
         TlinP t;
         t.X = in->text; t.ldx = Dt; t.M = (long)B * T; t.W = WB(n, n.te_w); t.ldw = Dt; t.bias = w + n.te_b;
         t.Y = a.tok; t.ldy = E; t.N = E; t.K = Dt;
@@ -566,7 +597,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // modulo the un-replicated size) neither the R-fold copy of x0 nor R-1 of the R projections exist.
     // the text tokens carry no dropout: their I2T K / V projection is the same for every replica
     static const bool no_i2t_share = getenv("GG_NO_I2T_SHARE") != nullptr;
-    a.i2t_shared = !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
+    a.i2t_shared = e->xattn && !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
     const bool share0 = R > 1 && bst && e->wgrad_on && (long)B * S >= 4096;      // (the weight-gradient kernel must engage)
     a.share0 = share0;
     const float* x_in = a.x0;
@@ -577,7 +608,8 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             x_in = a.xrep;
         }
         // shared I2T keys: only the text CLS row (token 0) of every replica is read from the replicated layout
-        if (a.i2t_shared) KL(k_copy_rows_strided_bcast(a.tokrep, (long)T * E, a.tok, (long)T * E, RB, B, E, c.st));
+        if (!e->xattn) {
+        } else if (a.i2t_shared) KL(k_copy_rows_strided_bcast(a.tokrep, (long)T * E, a.tok, (long)T * E, RB, B, E, c.st));
         else KL(k_copy_rows_bcast(a.tokrep, a.tok, RB * T, (long)B * T, E, c.st));
         tok = a.tokrep;
     }
@@ -653,6 +685,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             });
         }
         x_in = L.x2;
+    }
+    if (!e->xattn) {    // conditioning vector = the encoder's CLS row (conditional_gan_film.py:150)
+        KL(k_copy_rows_strided_bcast(a.c, E, x_in, (long)S * E, RB, RB, E, c.st));
+        return 0;
     }
     // T2I: query = text CLS embedding, keys = values = encoder output (R:218)
     GG_TRY(lin_fwd(c, tok, (long)T * E, w + n.t2i.inw, E, w + n.t2i.inb, a.t2i_q, E, (int)RB, E, E));
@@ -757,6 +793,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const float ks = drop > 0.f ? 1.f / (1.f - drop) : 1.f;
     const int bst = a.bst ? 1 : 0;
 
+    bool i2t_sh = false;
+    if (!e->xattn) {    // the conditioning vector was the encoder's CLS row: its gradient is the only non-zero row per sample
+        KL(k_fill(e->sdx, RB * S * E, 0.f, c.st));
+        KL(k_copy_rows_strided_bcast(e->sdx, (long)S * E, dc, E, RB, RB, E, c.st));
+    } else {
     // ---- I2T backward: t = out_proj(ctx); scores over text tokens; q from p -----------------------
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;
@@ -766,7 +807,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_tmpE, E, (int)RB, E, E));
-    const bool i2t_sh = a.i2t_shared && sq_attn_shared_ok(T, E, nh, Rb);
+    i2t_sh = a.i2t_shared && sq_attn_shared_ok(T, E, nh, Rb);
     GG_REQUIRE(i2t_sh || !a.i2t_shared, "shared I2T keys: backward replica count not supported");
     if (i2t_sh) KL(k_sq_attn_bwd_shared(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, B, Rb, T, E, nh, c.st));
     else KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
@@ -859,6 +900,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E)));
         }
     }
+    }   // xattn
     // ---- encoder layers, last to first ---------------------------------------------------------------
     float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
     for (int l = e->nl - 1; l >= 0; --l) {
@@ -987,7 +1029,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const float* dtok = e->s_dtokrep;
     if (Rb > 1) {
         KL(k_fold(e->s_dx0, dx, (long)B * S * E, Rb, c.st));
-        if (!i2t_sh) KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
+        if (e->xattn && !i2t_sh) KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
         dx0 = e->s_dx0;
         if (!i2t_sh) dtok = e->s_dtok;
     }
@@ -1024,8 +1066,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     KL(k_film_act_bwd(e->s_dgb, a.gb, a.gbpre, B, Dp, c.st));
     GG_TRY(lin_bwd_weight(c, e->s_dgb, 2 * Dp, in->text, (long)T * Dt, g + n.film_w, Dt, B, 2 * Dp, Dt));
     KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));
-    GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
-    KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
+    if (e->xattn) {
+        GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
+        KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
+    }
     for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     return 0;
 }
@@ -1117,9 +1161,9 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
     GG_REQUIRE(e->cfg.optimizer == GG_OPT_RMSPROP || n.s2, "Adam needs the second state buffer");
     float* ss = e->sumsq + n.role;
     KL(k_fill(ss, 1, 0.f, c.st));
-    if (max_norm > 0.f) KL(k_sumsq(n.g, n.total, ss, c.st));
+    if (max_norm > 0.f) KL(k_sumsq(n.g, n.live, ss, c.st));
     n.step_t += 1;
-    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.total, e->cfg.optimizer, n.lr, max_norm, ss, grad_scale, n.step_t, c.st));
+    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.live, e->cfg.optimizer, n.lr, max_norm, ss, grad_scale, n.step_t, c.st));
     return 0;
 }
 
@@ -1343,6 +1387,8 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->cfg = *cfg;
     e->E = cfg->embedding_dims; e->F = 2 * e->E; e->H = cfg->hidden_dims; e->G = cfg->n_genes; e->L = cfg->latent_dims;
     e->Dt = cfg->text_dims; e->Dp = cfg->patch_dims; e->nh = cfg->n_heads; e->nl = cfg->n_layers; e->dh = e->E / e->nh;
+    e->xattn = cfg->variant != GG_VARIANT_FILM;
+    e->enc_bias = cfg->variant != GG_VARIANT_FILM;
     e->maxB = cfg->max_batch; e->maxP = cfg->max_patches; e->maxT = cfg->max_text_tokens; e->maxS = e->maxP + 1;
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
     e->dropout = cfg->dropout;

@@ -28,7 +28,7 @@ class Engine:
     def __init__(self, *, n_genes, latent_dims, embedding_dims, hidden_dims, text_dims, patch_dims,
                  n_heads=4, n_layers=2, negative_slope=0.0, dropout=0.1, lr_d=5e-4, lr_g=5e-4,
                  optimizer="rms_prop", gp_weight=10.0, clip_d=10.0, clip_g=2.0, max_batch=8, max_patches=256,
-                 max_text_tokens=1, seed=0, device="cuda:0", precision="f32"):
+                 max_text_tokens=1, seed=0, device="cuda:0", precision="f32", variant="xattn_film"):
         self.lib = L.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -36,8 +36,9 @@ class Engine:
         self.cfg = L.GGConfig(n_genes, latent_dims, embedding_dims, hidden_dims, text_dims, patch_dims, n_heads,
                               n_layers, negative_slope, dropout, lr_d, lr_g, L.OPT_KINDS[optimizer.lower()], gp_weight,
                               clip_d if clip_d else 0.0, clip_g if clip_g else 0.0, max_batch, max_patches,
-                              max_text_tokens, seed, L.PRECISIONS[precision])
+                              max_text_tokens, seed, L.PRECISIONS[precision], L.VARIANTS[variant])
         self.precision = precision
+        self.variant = variant
         self.h = C.c_void_p()
         L.check(self.lib.gg_create(C.byref(self.cfg), C.byref(self.h)))
         self.layout = {r: self._read_layout(r) for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC)}

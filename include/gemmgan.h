@@ -46,6 +46,11 @@ extern "C" {
 #define GG_LOSS_G 3      /* mean(-D(G(z)))     R:36  */
 #define GG_N_LOSSES 8
 
+/* model variants: the same engine, parametrised */
+#define GG_VARIANT_XATTN_FILM 0 /* src/conditional_gan_cross_attention_with_film.py: FiLM + encoder + T2I/I2T cross attention  */
+#define GG_VARIANT_FILM 1       /* src/conditional_gan_film.py:97-205: FiLM + bias-free encoder (R':115 bias=False), the   */
+                                /* conditioning vector is the encoder's CLS row (R':150); text is one vector per sample (T=1) */
+
 typedef struct gg_config {
     /* model shape: WGAN_GP.__init__ kwargs R:258-271, generator/discriminator ctors R:99, R:169 */
     int32_t n_genes;        /* input_dims / vector_dims (G)                           */
@@ -69,6 +74,7 @@ typedef struct gg_config {
     int32_t max_text_tokens;/* T */
     uint64_t seed;          /* dropout stream seed (z / alpha are supplied by the caller) */
     int32_t precision;      /* GG_PREC_* */
+    int32_t variant;        /* GG_VARIANT_*: which reference model file the networks follow */
 } gg_config;
 
 typedef struct gg_engine gg_engine;

@@ -53,10 +53,22 @@ class PathConfig:
     n_critic: int = 5
     clip_d: Optional[float] = 10.0   # :414
     clip_g: Optional[float] = 2.0    # :457
+    # "xattn_film": src/conditional_gan_cross_attention_with_film.py (line numbers above and below);
+    # "film": src/conditional_gan_film.py - no token encoder / cross attention, the conditioning vector is the encoder's
+    # CLS row (F:150), bias-free encoder layers (F:115 bias=False), no gradient clipping (F:383-385): use
+    # film_config() so the clip fields follow
+    variant: str = "xattn_film"
 
     @property
     def ffn_dims(self) -> int:
         return 2 * self.embedding_dims   # dim_feedforward=E*2, :115
+
+
+def film_config(**kw) -> PathConfig:
+    """PathConfig of the FiLM-only sibling (src/conditional_gan_film.py): no clipping, reference default text width."""
+    kw.setdefault("clip_d", None)
+    kw.setdefault("clip_g", None)
+    return PathConfig(variant="film", **kw)
 
 
 def _mlp_block(n_in: int, n_out: int, slope: float) -> nn.Sequential:
@@ -76,18 +88,22 @@ class CondNet(nn.Module):
         assert role in ("generator", "discriminator")
         self.role, self.cfg = role, cfg
         E, Dt, Dp = cfg.embedding_dims, cfg.text_dims, cfg.patch_dims
+        film_only = cfg.variant == "film"
+        assert cfg.variant in ("xattn_film", "film")
         self.film_generator = nn.Linear(Dt, 2 * Dp)
-        self.text_encoder = nn.Linear(Dt, E)
+        if not film_only:
+            self.text_encoder = nn.Linear(Dt, E)
         self.patches_encoder = nn.Linear(Dp, E)
         self.patches_transformer_layer = nn.TransformerEncoderLayer(
             d_model=E, nhead=cfg.n_heads, dim_feedforward=cfg.ffn_dims, dropout=cfg.dropout,
-            activation="relu", batch_first=True)
+            activation="relu", batch_first=True, bias=not film_only)      # F:113-115: bias=False
         self.patches_cls_token = nn.Parameter(torch.empty(1, 1, E))
         nn.init.trunc_normal_(self.patches_cls_token, std=0.02)
         self.patches_transformer = nn.TransformerEncoder(
             self.patches_transformer_layer, num_layers=cfg.n_layers)
-        self.patch2text_attention = nn.MultiheadAttention(E, cfg.n_heads, batch_first=True)
-        self.text2patch_attention = nn.MultiheadAttention(E, cfg.n_heads, batch_first=True)
+        if not film_only:
+            self.patch2text_attention = nn.MultiheadAttention(E, cfg.n_heads, batch_first=True)
+            self.text2patch_attention = nn.MultiheadAttention(E, cfg.n_heads, batch_first=True)
         first = (cfg.latent_dims if role == "generator" else cfg.n_genes) + E
         H = cfg.hidden_dims
         blocks = nn.ModuleList([_mlp_block(first, H, cfg.negative_slope),
@@ -102,12 +118,17 @@ class CondNet(nn.Module):
         gamma = torch.tanh(gb[:, :Dp])
         beta = torch.clamp(gb[:, Dp:], min=-5.0, max=5.0)
         mod = gamma[:, None, :] * patches + beta[:, None, :]
-        tok = self.text_encoder(text)
         emb = self.patches_encoder(mod)
         B = emb.shape[0]
         seq = torch.cat((self.patches_cls_token.expand(B, -1, -1), emb), dim=1)
         mask = torch.cat((patch_pad.new_zeros(B, 1, dtype=torch.bool), patch_pad), dim=1)
         enc = self.patches_transformer(seq, src_key_padding_mask=mask)
+        if self.cfg.variant == "film":      # F:130-152: text is one vector per sample (here [B,1,Dt]); c = CLS row
+            c = enc[:, 0, :]
+            if taps is not None:
+                taps.update(gamma=gamma, beta=beta, seq0=seq, enc=enc, cond=c)
+            return c
+        tok = self.text_encoder(text)
         p, _ = self.patch2text_attention(tok[:, 0:1, :], enc, enc, key_padding_mask=mask)
         t, _ = self.text2patch_attention(p[:, 0:1, :], tok, tok, key_padding_mask=text_pad)
         c = t[:, 0, :] + p[:, 0, :]

@@ -65,7 +65,7 @@ def engine_from_cfg(cfg, B, P, T, dropout=0.0, seed=0, optimizer=None):
                   n_heads=cfg.n_heads, n_layers=cfg.n_layers, negative_slope=cfg.negative_slope, dropout=dropout,
                   lr_d=cfg.lr_d, lr_g=cfg.lr_g, optimizer=optimizer or cfg.optimizer, gp_weight=cfg.gp_weight,
                   clip_d=cfg.clip_d or 0.0, clip_g=cfg.clip_g or 0.0, max_batch=B, max_patches=P, max_text_tokens=T,
-                  seed=seed, device="cuda:0")
+                  seed=seed, device="cuda:0", variant=getattr(cfg, "variant", "xattn_film"))
 
 
 def load_oracle_state(eng, trainer):

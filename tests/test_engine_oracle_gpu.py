@@ -7,7 +7,7 @@ import torch
 
 from gemm_gan_amd import _lib as L
 from gpu_util import Checker, dev, engine_from_cfg, load_oracle_state
-from oracle.torch_oracle import PathConfig, Trainer, set_dropout, synthetic_batch
+from oracle.torch_oracle import PathConfig, Trainer, film_config, set_dropout, synthetic_batch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -23,6 +23,11 @@ CASES = {
     # 77 = four 16-key rounds + a ragged 13
     "text_T77_E256": dict(cfg=PathConfig(n_genes=120, latent_dims=32, embedding_dims=256, hidden_dims=64, text_dims=48,
                                           patch_dims=40, dropout=0.0), B=5, P=20, T=77),
+    # FiLM-only sibling (src/conditional_gan_film.py): bias-free encoder, CLS-row conditioning, no clip
+    "film_P1": dict(cfg=film_config(n_genes=150, latent_dims=32, embedding_dims=64, hidden_dims=48, text_dims=40,
+                                    patch_dims=56, dropout=0.0), B=9, P=1, T=1),
+    "film_P33_E256": dict(cfg=film_config(n_genes=90, latent_dims=24, embedding_dims=256, hidden_dims=64, text_dims=48,
+                                          patch_dims=64, dropout=0.0), B=4, P=33, T=1),
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
@@ -78,7 +83,7 @@ def test_critic_and_generator_iteration_vs_autograd(case):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256"])
+@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256"])
 def test_replica_stacked_passes_vs_autograd(case):
     """With dropout on, the three critic passes of an iteration run as replicas stacked on the batch axis (two of them
     carry gradient; shared layer inputs, shared text keys, replica-summed gradients).  A drop probability of 1e-7 keeps
