@@ -10,7 +10,8 @@ What it does
   * registers inert stand-ins in ``sys.modules`` for evaluation-only third-party imports the
     image lacks (lightgbm, umap, seaborn, catboost, ot, torch_geometric ...; none is touched by
     the model/trainer code) and imports
-    ``/root/reference/src/conditional_gan_cross_attention_with_film.py`` unmodified,
+    ``/root/reference/src/conditional_gan_cross_attention_with_film.py`` (and, for the FiLM-only sibling fixtures,
+    ``/root/reference/src/conditional_gan_film.py``) unmodified,
   * zeroes every dropout probability (bitwise RNG parity with torch dropout is not a goal;
     parity runs are p=0, SURVEY.md section 7 "Hard parts" (b)),
   * records - without editing the reference - the ``z`` / ``alpha`` draws (wrapping
@@ -24,6 +25,7 @@ Only DATA leaves this container: no reference source text is written anywhere.
 from __future__ import annotations
 
 import copy
+import importlib
 import importlib.machinery
 import os
 import sys
@@ -43,7 +45,7 @@ class _Inert(types.ModuleType):
         return type(name, (), {})
 
 
-def import_reference():
+def import_reference(module="conditional_gan_cross_attention_with_film"):
     for m in ["lightgbm", "umap", "seaborn", "catboost", "ot", "rnaseq_contrastive_model",
               "torch_geometric", "torch_geometric.nn", "geomloss", "timm", "openslide"]:
         if m not in sys.modules:
@@ -53,8 +55,7 @@ def import_reference():
             sys.modules[m] = mod
     if REF_SRC not in sys.path:
         sys.path.insert(0, REF_SRC)
-    import conditional_gan_cross_attention_with_film as ref   # noqa: E402
-    return ref
+    return importlib.import_module(module)
 
 
 def zero_dropout(net):
@@ -130,6 +131,42 @@ def sd_to_np(prefix, sd, out, stride=1):
         out[f"{prefix}/{k}"] = a if stride == 1 else a.reshape(-1)[::stride].copy()
 
 
+class Calls:
+    """The two reference files differ in argument order / text rank; fixtures store text as [B,T,Dt] for both."""
+
+    def __init__(self, film):
+        self.film = film
+
+    def net(self, net, v, inp):
+        if self.film:       # conditional_gan_film.py:130 / :183: (x, text_embedding [B,Dt], patches, padding_mask)
+            return net(v, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
+        return net(v, inp["patches"], inp["patch_pad"], inp["text"], inp["text_pad"])
+
+    def train_disc(self, w, x, z, inp):
+        if self.film:
+            return w.train_disc(x, z, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
+        return w.train_disc(x, z, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
+
+    def train_gen(self, w, z, inp):
+        if self.film:
+            return w.train_gen(z, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
+        return w.train_gen(z, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
+
+    def train(self, w, x, inp):
+        if self.film:
+            return w.train(x, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
+        return w.train(x, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
+
+    def generate(self, w, x, inp):
+        if self.film:
+            return w.generate_samples(x, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
+        return w.generate_samples(x, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
+
+
+def grads_of(net):
+    return [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+
+
 def build(ref, dims, optimizer, init=None):
     w = ref.WGAN_GP(dims["G"], dims["L"], dims["E"], [dims["H"], dims["H"], dims["G"]],
                     [dims["H"], dims["H"], 1], text_embedding_dims=dims["Dt"],
@@ -153,12 +190,14 @@ def stage_hooks(net, role, taps):
             taps[name] = pick(o).detach().clone()
         return fn
     hs.append(net.film_generator.register_forward_hook(tap("film_pre")))
-    hs.append(net.text_encoder.register_forward_hook(tap("text_enc")))
+    if hasattr(net, "text_encoder"):
+        hs.append(net.text_encoder.register_forward_hook(tap("text_enc")))
     hs.append(net.patches_encoder.register_forward_hook(tap("patch_emb")))
     for i, layer in enumerate(net.patches_transformer.layers):
         hs.append(layer.register_forward_hook(tap(f"enc_layer{i}")))
-    hs.append(net.patch2text_attention.register_forward_hook(tap("t2i", lambda o: o[0][:, 0, :])))
-    hs.append(net.text2patch_attention.register_forward_hook(tap("i2t", lambda o: o[0][:, 0, :])))
+    if hasattr(net, "patch2text_attention"):
+        hs.append(net.patch2text_attention.register_forward_hook(tap("t2i", lambda o: o[0][:, 0, :])))
+        hs.append(net.text2patch_attention.register_forward_hook(tap("i2t", lambda o: o[0][:, 0, :])))
     blocks = getattr(net, role)
     for i, blk in enumerate(blocks):
         hs.append(blk[0].register_forward_hook(tap(f"mlp_pre{i}")))
@@ -171,6 +210,9 @@ def make_fixture(ref, name, dims, seed):
     out["dims"] = np.array([dims[k] for k in ("B", "G", "P", "T", "Dt", "Dp", "E", "H", "L", "n_critic")],
                            dtype=np.int64)
     out["slope"] = np.float32(dims.get("slope", 0.0))
+    film = dims.get("variant", "xattn_film") == "film"
+    out["variant"] = np.array(dims.get("variant", "xattn_film"))
+    call = Calls(film)
     torch.manual_seed(seed)
     w0 = build(ref, dims, "rms_prop")
     init = (copy.deepcopy(w0.gen.state_dict()), copy.deepcopy(w0.disc.state_dict()))
@@ -187,7 +229,7 @@ def make_fixture(ref, name, dims, seed):
     taps = {}
     hs = stage_hooks(w0.disc, "discriminator", taps)
     with torch.no_grad():
-        w0.disc(x, patches, patch_pad, text, text_pad)
+        call.net(w0.disc, x, inp)
     for h in hs:
         h.remove()
     for k, v in taps.items():
@@ -197,7 +239,7 @@ def make_fixture(ref, name, dims, seed):
     taps = {}
     hs = stage_hooks(w0.gen, "generator", taps)
     with torch.no_grad():
-        w0.gen(z0, patches, patch_pad, text, text_pad)
+        call.net(w0.gen, z0, inp)
     for h in hs:
         h.remove()
     out["gen_fwd/z"] = z0.numpy()
@@ -206,7 +248,7 @@ def make_fixture(ref, name, dims, seed):
     # eval-mode inference (generate_samples, :601-608) with z recorded
     torch.manual_seed(seed + 3)
     with Recorder() as rec:
-        _, x_gen = w0.generate_samples(x, text, text_pad, patches, patch_pad)
+        _, x_gen = call.generate(w0, x, inp)
     out["infer/z"] = rec.z[0].numpy()
     out["infer/x_gen"] = x_gen.numpy()
 
@@ -215,13 +257,16 @@ def make_fixture(ref, name, dims, seed):
     z1 = torch.randn(dims["B"], dims["L"], generator=g)
     torch.manual_seed(seed + 4)
     with Recorder() as rec:
-        w1.train_disc(x, z1, text, text_pad, patches, patch_pad)
+        call.train_disc(w1, x, z1, inp)
     out["critic1/z"] = z1.numpy()
     out["critic1/alpha"] = rec.alpha[0].numpy()
     out["critic1/grad_x_hat"] = rec.gp_grads[0].numpy()
     out["critic1/losses"] = np.array([float(w1.disc_loss), *w1.d_batch_loss], dtype=np.float64)
-    pre, tot, mx = rec.clips[0]
-    out["critic1/grad_total_norm"] = np.float64(tot)
+    if film:        # no clipping in this file (conditional_gan_film.py:383-385): the gradients are still on the parameters
+        pre = grads_of(w1.disc)
+    else:
+        pre, tot, mx = rec.clips[0]
+        out["critic1/grad_total_norm"] = np.float64(tot)
     for (n, _p), gpre in zip(w1.disc.named_parameters(), pre):
         if gpre is not None:
             out[f"critic1/grad/{n}"] = gpre.numpy()
@@ -233,11 +278,14 @@ def make_fixture(ref, name, dims, seed):
     w2 = build(ref, dims, "rms_prop", init)
     z2 = torch.randn(dims["B"], dims["L"], generator=g)
     with Recorder() as rec:
-        w2.train_gen(z2, text, text_pad, patches, patch_pad)
+        call.train_gen(w2, z2, inp)
     out["gen1/z"] = z2.numpy()
     out["gen1/loss"] = np.float64(float(w2.gen_loss))
-    pre, tot, mx = rec.clips[0]
-    out["gen1/grad_total_norm"] = np.float64(tot)
+    if film:
+        pre = grads_of(w2.gen)
+    else:
+        pre, tot, mx = rec.clips[0]
+        out["gen1/grad_total_norm"] = np.float64(tot)
     for (n, _p), gpre in zip(w2.gen.named_parameters(), pre):
         if gpre is not None:
             out[f"gen1/grad/{n}"] = gpre.numpy()
@@ -248,7 +296,7 @@ def make_fixture(ref, name, dims, seed):
         w = build(ref, dims, opt, init)
         torch.manual_seed(seed + 5)
         with Recorder() as rec:
-            w.train(x, text, text_pad, patches, patch_pad)
+            call.train(w, x, inp)
         assert len(rec.z) == dims["n_critic"] + 1 and len(rec.alpha) == dims["n_critic"]
         out[f"step_{opt}/z"] = np.stack([t.numpy() for t in rec.z])
         out[f"step_{opt}/alpha"] = np.stack([t.numpy() for t in rec.alpha])
@@ -272,13 +320,20 @@ FIXTURES = {
     "xattn_film_T3": dict(B=5, G=37, P=6, T=3, Dt=24, Dp=40, E=32, H=32, L=16, n_critic=5),
     # the BASELINE shape family in miniature: single text token, slope != 0 exercises LeakyReLU
     "xattn_film_T1_leaky": dict(B=4, G=50, P=9, T=1, Dt=16, Dp=24, E=32, H=24, L=8, n_critic=2, slope=0.2),
+    # FiLM-only sibling (src/conditional_gan_film.py; BASELINE configs[1]: one patch, text vector)
+    "film_P1": dict(B=6, G=41, P=1, T=1, Dt=20, Dp=28, E=32, H=24, L=12, n_critic=5, variant="film"),
+    "film_P7": dict(B=4, G=33, P=7, T=1, Dt=16, Dp=24, E=32, H=16, L=8, n_critic=2, variant="film", slope=0.1),
 }
 
 
 def main():
     torch.set_num_threads(1)           # bit-reproducible reductions
-    ref = import_reference()
+    only = set(sys.argv[1:])
     for i, (name, dims) in enumerate(FIXTURES.items()):
+        if only and name not in only:
+            continue
+        film = dims.get("variant") == "film"
+        ref = import_reference("conditional_gan_film" if film else "conditional_gan_cross_attention_with_film")
         make_fixture(ref, name, dims, seed=1234 + 100 * i)
 
 

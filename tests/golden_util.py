@@ -4,10 +4,11 @@ import os
 import numpy as np
 import torch
 
-from oracle.torch_oracle import CondNet, PathConfig, Trainer, set_dropout
+from oracle.torch_oracle import CondNet, PathConfig, Trainer, film_config, set_dropout
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky"]
+# xattn_film_*: from src/conditional_gan_cross_attention_with_film.py; film_*: from src/conditional_gan_film.py
+FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky", "film_P1", "film_P7"]
 
 
 class Golden:
@@ -18,10 +19,12 @@ class Golden:
                      (int(v) for v in self.z["dims"])))
         self.dims = d
         self.slope = float(self.z["slope"])
+        self.variant = str(self.z["variant"]) if "variant" in self.z.files else "xattn_film"
 
     def cfg(self, optimizer="rms_prop") -> PathConfig:
         d = self.dims
-        return PathConfig(n_genes=d["G"], latent_dims=d["L"], embedding_dims=d["E"], hidden_dims=d["H"],
+        make = film_config if self.variant == "film" else PathConfig
+        return make(n_genes=d["G"], latent_dims=d["L"], embedding_dims=d["E"], hidden_dims=d["H"],
                           text_dims=d["Dt"], patch_dims=d["Dp"], negative_slope=self.slope, dropout=0.0,
                           optimizer=optimizer, n_critic=d["n_critic"])
 

@@ -43,12 +43,14 @@ def test_forward_stages(name):
     gb = eng.debug_buffer("D.gb").view(B, 2 * Dp)
     ck.check("film gamma", gb[:, :Dp], np.tanh(ref["film_pre"][:, :Dp]))
     ck.check("film beta", gb[:, Dp:], np.clip(ref["film_pre"][:, Dp:], -5, 5))
-    ck.check("text encoder", eng.debug_buffer("D.tok").view(B, d["T"], E), ref["text_enc"])
+    if g.variant != "film":
+        ck.check("text encoder", eng.debug_buffer("D.tok").view(B, d["T"], E), ref["text_enc"])
     ck.check("patch encoder (FiLM fused)", eng.debug_buffer("D.x0").view(B, S, E)[:, 1:], ref["patch_emb"])
     ck.check("encoder layer 0", eng.debug_buffer("D.L0.x2").view(B, S, E), ref["enc_layer0"])
     ck.check("encoder layer 1", eng.debug_buffer("D.L1.x2").view(B, S, E), ref["enc_layer1"])
-    ck.check("T2I attention", eng.debug_buffer("D.t2i_out").view(B, E), ref["t2i"])
-    ck.check("I2T attention", eng.debug_buffer("D.i2t_out").view(B, E), ref["i2t"])
+    if g.variant != "film":
+        ck.check("T2I attention", eng.debug_buffer("D.t2i_out").view(B, E), ref["t2i"])
+        ck.check("I2T attention", eng.debug_buffer("D.i2t_out").view(B, E), ref["i2t"])
     ck.check("critic score", out, ref["out"])
     xg = eng.forward(L.ROLE_GENERATOR, g.t("gen_fwd/z").cuda(), patches, patch_pad, text, text_pad, train=True)
     ck.check("generated genes", xg, g.z["gen_fwd/out"])

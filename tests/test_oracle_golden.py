@@ -25,7 +25,8 @@ def test_state_dict_keys_and_dead_layer(name):
     assert set(tr.gen.state_dict()) == set(g.group("init_gen"))
     assert set(tr.disc.state_dict()) == set(g.group("init_disc"))
     dead = [k for k in g.group("critic1/grad_none")]
-    assert len(dead) == 12 and all(k.startswith("patches_transformer_layer.") for k in dead)
+    n_dead = 6 if g.variant == "film" else 12       # the template layer of the bias-free encoder has weights only
+    assert len(dead) == n_dead and all(k.startswith("patches_transformer_layer.") for k in dead)
     assert not any(n.startswith("patches_transformer_layer.") for n, _ in live_parameters(tr.disc))
 
 
@@ -42,11 +43,12 @@ def test_forward_stages(name):
     Dp = g.dims["Dp"]
     assert rel_err(taps["gamma"], np.tanh(ref["film_pre"][:, :Dp])) < TOL
     assert rel_err(taps["beta"], np.clip(ref["film_pre"][:, Dp:], -5, 5)) < TOL
-    assert rel_err(taps["text_enc"], ref["text_enc"]) < TOL
     assert rel_err(taps["seq0"][:, 1:], ref["patch_emb"]) < TOL
     assert rel_err(taps["enc"], ref["enc_layer1"]) < TOL
-    assert rel_err(taps["t2i"], ref["t2i"]) < TOL
-    assert rel_err(taps["i2t"], ref["i2t"]) < TOL
+    if g.variant != "film":
+        assert rel_err(taps["text_enc"], ref["text_enc"]) < TOL
+        assert rel_err(taps["t2i"], ref["t2i"]) < TOL
+        assert rel_err(taps["i2t"], ref["i2t"]) < TOL
     assert rel_err(taps["mlp_pre0"], ref["mlp_pre0"]) < TOL
     assert rel_err(taps["mlp_pre1"], ref["mlp_pre1"]) < TOL
     assert rel_err(out, ref["out"]) < TOL
@@ -67,7 +69,10 @@ def test_critic_iteration(name):
     los = g.z["critic1/losses"]
     assert rel_err([r["total"].item(), r["d_loss"].item(), r["d_real"].item(), r["d_fake"].item()], los) < TOL
     assert rel_err(r["grad_x_hat"].detach(), g.z["critic1/grad_x_hat"]) < TOL
-    assert abs(float(r["grad_norm_total"]) - float(g.z["critic1/grad_total_norm"])) < 1e-5 * float(g.z["critic1/grad_total_norm"])
+    if g.variant != "film":     # the FiLM-only file does not clip
+        assert abs(float(r["grad_norm_total"]) - float(g.z["critic1/grad_total_norm"])) < 1e-5 * float(g.z["critic1/grad_total_norm"])
+    else:
+        assert "grad_norm_total" not in r
     for n, ref in g.group("critic1/grad").items():
         assert rel_err(r["grads"][n], ref) < 1e-5, n
     for n in g.group("critic1/grad_none"):
