@@ -40,6 +40,7 @@ class _CondNet(nn.Module):
     """Parameter container with the reference's attribute names + engine-backed forward."""
 
     _role = None          # 'generator' | 'discriminator'
+    _variant = "xattn_film"   # engine variant (film.py overrides: "film")
 
     def __init__(self, first_dims, embedding_dims, mlp_dims, text_embedding_dims=768,
                  patches_embedding_dims=1024, negative_slope=0.0, is_bn=False):
@@ -54,16 +55,20 @@ class _CondNet(nn.Module):
         self.is_bn = is_bn
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         # construction order == reference order (R:111-126), so a given torch seed gives the same init
+        film_only = self._variant == "film"      # src/conditional_gan_film.py:111-124: no token encoder / cross attention
         self.film_generator = nn.Linear(text_embedding_dims, patches_embedding_dims * 2)
-        self.text_encoder = nn.Linear(text_embedding_dims, E)
+        if not film_only:
+            self.text_encoder = nn.Linear(text_embedding_dims, E)
         self.patches_encoder = nn.Linear(patches_embedding_dims, E)
         self.patches_transformer_layer = nn.TransformerEncoderLayer(
-            d_model=E, nhead=4, dim_feedforward=E * 2, dropout=0.1, activation="relu", batch_first=True)
+            d_model=E, nhead=4, dim_feedforward=E * 2, dropout=0.1, activation="relu", batch_first=True,
+            bias=not film_only)
         self.patches_cls_token = nn.Parameter(torch.empty(1, 1, E))
         torch.nn.init.trunc_normal_(self.patches_cls_token, std=0.02)
         self.patches_transformer = nn.TransformerEncoder(self.patches_transformer_layer, num_layers=2)
-        self.patch2text_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
-        self.text2patch_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
+        if not film_only:
+            self.patch2text_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
+            self.text2patch_attention = nn.MultiheadAttention(embed_dim=E, num_heads=4, batch_first=True)
         self.input_dims = first_dims + E
         dims = list(mlp_dims)
         blocks = nn.ModuleList()
@@ -155,6 +160,9 @@ class _EngineOptimizer:
 
 
 class WGAN_GP:
+    _variant = "xattn_film"       # engine variant
+    _clip = (10.0, 2.0)           # clip_grad_norm_ max_norm of the critic / generator step (R:414, R:457)
+
     def __init__(self, input_dims, latent_dims, embedding_dims, generator_dims, discriminator_dims,
                  text_embedding_dims=768, patches_embedding_dims=1024, negative_slope=0.0, is_bn=False,
                  lr_d=5e-4, lr_g=5e-4, optimizer="rms_prop", gp_weight=10, p_aug=0, norm_scale=0.5, train=True,
@@ -206,10 +214,13 @@ class WGAN_GP:
         self.optimizer_disc = self.optimizer_gen = None
 
     # ---- construction (R:334-349, R:320-331) -------------------------------------------------------
+    def _build_nets(self):
+        return WGAN_GP_model(self.latent_dims, self.input_dims, self.embedding_dims, self.generator_dims,
+                             self.discriminator_dims, self.text_embedding_dims, self.patches_embedding_dims,
+                             self.negative_slope, self.is_bn)
+
     def build_WGAN_GP(self):
-        self.gen, self.disc = WGAN_GP_model(self.latent_dims, self.input_dims, self.embedding_dims, self.generator_dims,
-                                            self.discriminator_dims, self.text_embedding_dims, self.patches_embedding_dims,
-                                            self.negative_slope, self.is_bn)
+        self.gen, self.disc = self._build_nets()
         if self.device.type != "cuda":
             raise RuntimeError("gemm_gan_amd.WGAN_GP needs a ROCm GPU: there is no CPU fallback "
                                "(use oracle/torch_oracle.py for CPU checks)")
@@ -227,7 +238,8 @@ class WGAN_GP:
                      hidden_dims=H, text_dims=self.text_embedding_dims, patch_dims=self.patches_embedding_dims,
                      negative_slope=self.negative_slope, dropout=self.dropout, lr_d=self.lr_d, lr_g=self.lr_g,
                      optimizer=self.optimizer, gp_weight=float(self.gp_weight), max_batch=B, max_patches=P,
-                     max_text_tokens=T, seed=self.seed, device=self.device, precision=self.precision)
+                     max_text_tokens=T, seed=self.seed, device=self.device, precision=self.precision,
+                     variant=self._variant, clip_d=self._clip[0], clip_g=self._clip[1])
         eng._owner = self
         if old is not None:          # grow: keep parameters, gradients, optimiser state and step counters
             for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
@@ -390,6 +402,9 @@ class WGAN_GP:
             x_gen = self.gen(z, patches, padding_mask, text_embedding, text_padding)
         return x_real, x_gen
 
+    def _fit_batch(self, data):
+        self.train(data[2], data[0], data[1], data[3], data[4])             # R:667-673
+
     # ---- epoch loop (R:619-711): training, LR halving, loss bookkeeping, checkpoints ----------------------------
     def fit(self, train_data, val_data=None, test_data=None, epochs=1, val=False):
         """Training part of the reference fit(): evaluation/plots (R:712-894) are out of scope."""
@@ -404,7 +419,7 @@ class WGAN_GP:
             self.epoch = epoch
             d_loss_all, d_batch_loss, g_batch_loss, nb = 0.0, None, None, 0
             for i, data in enumerate(train_data):
-                self.train(data[2], data[0], data[1], data[3], data[4])             # R:667-673
+                self._fit_batch(data)
                 d_loss_all += self.disc_loss.item()
                 d_batch_loss = self.d_batch_loss if d_batch_loss is None else d_batch_loss + self.d_batch_loss
                 g_batch_loss = self.g_batch_loss if g_batch_loss is None else g_batch_loss + self.g_batch_loss

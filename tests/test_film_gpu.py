@@ -1,0 +1,84 @@
+"""Host-side mirror of the FiLM-only sibling (gemm_gan_amd/film.py <-> the reference's src/conditional_gan_film.py)
+against the golden vectors produced by that reference file (tests/golden/film_*.npz, oracle/make_golden.py): class
+surface, state_dict keys, a full train() with the recorded noise, eval-mode inference, fit() + checkpoints."""
+import numpy as np
+import pytest
+import torch
+
+from gemm_gan_amd import film
+from golden_util import Golden
+from gpu_util import Checker
+
+pytestmark = pytest.mark.gpu
+FILM_FIXTURES = ["film_P1", "film_P7"]
+
+
+def build(g: Golden, opt="rms_prop", **kw):
+    d = g.dims
+    w = film.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
+                     patches_embedding_dims=d["Dp"], negative_slope=g.slope, optimizer=opt, n_critic=d["n_critic"],
+                     dropout=0.0, device="cuda:0", **kw)
+    w.build_WGAN_GP()
+    w.init_train()
+    return w
+
+
+@pytest.mark.parametrize("name", FILM_FIXTURES)
+def test_state_dict_keys_and_golden_train_step(name):
+    g = Golden(name)
+    w = build(g)
+    assert set(w.gen.state_dict()) == set(g.group("init_gen"))          # incl. the dead template layer, as upstream
+    assert set(w.disc.state_dict()) == set(g.group("init_disc"))
+    w.gen.load_state_dict(g.state("init_gen"))
+    w.disc.load_state_dict(g.state("init_disc"))
+    x, text, text_pad, patches, patch_pad = (t.cuda() for t in g.inputs())
+    ck = Checker(f"film mirror {name}", 1e-3)
+    # eval-mode inference through the reference's forward signature (x, text_embedding, patches, padding_mask)
+    w.gen.eval()
+    ck.check("generator forward (eval)", w.gen(g.t("infer/z").cuda(), text[:, 0, :], patches, patch_pad), g.z["infer/x_gen"])
+    w.disc.train()
+    ck.check("critic forward (train)", w.disc(x, text[:, 0, :], patches, patch_pad), g.group("disc_fwd")["out"])
+    z_all = g.t("step_rms_prop/z").cuda().contiguous()
+    alpha_all = g.t("step_rms_prop/alpha").cuda().reshape(z_all.shape[0] - 1, -1).contiguous()
+    w.train_with_noise(x, text.contiguous(), text_pad, patches.contiguous(), patch_pad, z_all, alpha_all)
+    # several normalised-gradient steps: same gates as tests/test_engine_golden_gpu.py::test_full_train_step
+    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"], tol=5e-3)
+    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]), tol=5e-3)
+    lr = 5e-4
+    for role, net in (("gen", w.gen), ("disc", w.disc)):
+        sd = net.state_dict()
+        steps = 1 if role == "gen" else g.dims["n_critic"]
+        for n, ref in g.group(f"step_rms_prop/post_{role}").items():
+            if n.startswith("patches_transformer_layer."):
+                continue
+            got = sd[n].detach().cpu().numpy().reshape(-1)
+            init = g.z[f"init_{role}/{n}"].reshape(-1)
+            err = np.abs(got - ref.reshape(-1)).max()
+            assert err <= 0.25 * steps * lr * 10 + 1e-3 * np.abs(ref - init.reshape(ref.shape)).max() + 1e-6, (role, n, err)
+    ck.done()
+
+
+def test_reference_call_signatures_and_fit(tmp_path):
+    g = Golden("film_P7")
+    d = g.dims
+    w = build(g, results_dire=str(tmp_path))
+    x, text, text_pad, patches, patch_pad = g.inputs()
+    emb = text[:, 0, :]
+    z = torch.randn(d["B"], d["L"])
+    w.train_disc(x, z, emb, patches, patch_pad)
+    w.train_gen(z, emb, patches, patch_pad)
+    w.train(x, emb, patches, patch_pad)
+    assert np.isfinite(w.d_batch_loss).all() and np.isfinite(w.g_batch_loss).all()
+    x_real, x_gen = w.generate_samples(x, emb, patches, patch_pad)
+    assert tuple(x_gen.shape) == (d["B"], d["G"]) and torch.isfinite(x_gen).all()
+    w.freq_compute_test = 1
+    loader = [(emb, x, patches, patch_pad)] * 2                 # F:632-635 batch layout
+    w2 = film.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
+                      patches_embedding_dims=d["Dp"], n_critic=2, dropout=0.1, device="cuda:0", results_dire=str(tmp_path),
+                      freq_compute_test=1)
+    hist = w2.fit(loader, epochs=2)
+    assert len(hist["d loss"]) == 2 and all(np.isfinite(v) for v in hist["d loss"] + hist["g loss"])
+    sd = torch.load(tmp_path / "generator_last_epoch.pt")
+    assert set(sd) == set(g.group("init_gen"))                  # a checkpoint the reference's load_state_dict accepts
+    with pytest.raises(NotImplementedError):
+        w.gradient_penalty(x, x, emb, patches, patch_pad)
