@@ -35,7 +35,7 @@ def _create(g: Golden, **over):
     vals = dict(n_genes=d["G"], latent_dims=d["L"], embedding_dims=d["E"], hidden_dims=d["H"], text_dims=d["Dt"],
                 patch_dims=d["Dp"], n_heads=4, n_layers=2, negative_slope=g.slope, dropout=0.0, lr_d=5e-4, lr_g=5e-4,
                 optimizer=0, gp_weight=10.0, clip_d=10.0, clip_g=2.0, max_batch=d["B"], max_patches=d["P"],
-                max_text_tokens=d["T"], seed=0, precision=0)
+                max_text_tokens=d["T"], seed=0, precision=0, variant=L.VARIANTS[g.variant])
     vals.update(over)
     cfg = L.GGConfig(*[vals[f[0]] for f in L.GGConfig._fields_])
     h = C.c_void_p()
