@@ -9,6 +9,7 @@ from oracle.torch_oracle import CondNet, PathConfig, Trainer, film_config, set_d
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # xattn_film_*: from src/conditional_gan_cross_attention_with_film.py; film_*: from src/conditional_gan_film.py
 FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky", "film_P1", "film_P7"]
+XATTN_FIXTURES = [f for f in FIXTURES if f.startswith("xattn_")]
 
 
 class Golden:

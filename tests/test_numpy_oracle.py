@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import FIXTURES, Golden, comparable, rel_err
+from golden_util import XATTN_FIXTURES as FIXTURES, Golden, comparable, rel_err   # the numpy restatement covers the cross-attention file
 from oracle import numpy_oracle as no
 from oracle.torch_oracle import CondNet, PathConfig, Trainer, set_dropout, synthetic_batch
 
