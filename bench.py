@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--text-dims", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--variant", choices=["xattn_film", "film"], default="xattn_film",
+                    help="xattn_film: the headline path (conditional_gan_cross_attention_with_film.py); film: the FiLM-only "
+                         "sibling (conditional_gan_film.py; BASELINE configs[1] is --variant film --patches 1)")
     ap.add_argument("--pad-frac", type=float, default=0.0,
                     help="fraction of samples whose last P/4 patch tokens are padded (SURVEY 8d masking run: 0.25)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="bf16",
@@ -97,10 +100,11 @@ def log(msg):
 def cpu_baseline(args):
     """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
     bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 12 timed train() steps (about 20 s)."""
-    from oracle.torch_oracle import PathConfig, Trainer, synthetic_batch
+    from oracle.torch_oracle import PathConfig, Trainer, film_config, synthetic_batch
     cores = host_cores()
     torch.set_num_threads(cores)
-    cfg = PathConfig(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
+    make = film_config if args.variant == "film" else PathConfig
+    cfg = make(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
     Bc = args.cpu_batch
     torch.manual_seed(42)
     tr = Trainer(cfg)
@@ -157,7 +161,10 @@ def main():
     G, B, P, T = args.genes, args.batch, args.patches, args.tokens
     H = E = Lz = 256
     torch.manual_seed(42)                       # identical initial weights on every rank
-    w = gga.WGAN_GP(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
+    film = args.variant == "film"
+    if film and T != 1:
+        raise SystemExit("--variant film takes one text vector per sample (--tokens 1)")
+    w = (gga.film.WGAN_GP if film else gga.WGAN_GP)(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
                     optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="",
                     precision=args.precision)
     w.build_WGAN_GP()
@@ -171,6 +178,12 @@ def main():
     if args.pad_frac > 0:
         patch_pad[: int(round(B * args.pad_frac)), P - P // 4:] = True
     text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
+
+    def train_once():
+        if film:
+            w.train(x, text[:, 0, :], patches, patch_pad)
+        else:
+            w.train(x, text, text_pad, patches, patch_pad)
 
     def sync():
         if world > 1:
@@ -188,7 +201,7 @@ def main():
             w.engine.set_side_streams(False)
             w.engine.profile(True)
         t1 = time.perf_counter()
-        w.train(x, text, text_pad, patches, patch_pad)
+        train_once()
         torch.cuda.synchronize(dev)
         log(f"warm-up step {i}: {(time.perf_counter() - t1) * 1e3:.1f} ms")
         if prof and last:
@@ -206,7 +219,7 @@ def main():
     for i in range(args.steps):
         if prof and i == prof_steps:
             w.engine.profile_pause()
-        w.train(x, text, text_pad, patches, patch_pad)
+        train_once()
     sync()
     dt = time.perf_counter() - t0
     rows = []
@@ -222,11 +235,11 @@ def main():
     if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
         # the exact-fp32 path (f32-input MFMA, the mode the 1e-3 parity tests run in), same workload, 1 warm-up + 2 steps
         w.engine.set_precision("f32")
-        w.train(x, text, text_pad, patches, patch_pad)
+        train_once()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(2):
-            w.train(x, text, text_pad, patches, patch_pad)
+            train_once()
         torch.cuda.synchronize(dev)
         pdt = (time.perf_counter() - t1) / 2
         parity = {"dtype": "f32", "ms_per_step": round(pdt * 1e3, 3), "value": round(B / pdt, 2), "unit": "samples/s",
@@ -240,8 +253,9 @@ def main():
         out = {"metric": "WGAN-GP samples/sec (n_critic=5, 5k-gene)", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), "
-                                      f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
+               "config": {"workload": ("configs[1] family: conditional_gan_film.py train(), " if film else
+                                       "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), ")
+                                      + f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
                                       f"n_critic=5, rms_prop, dropout {args.dropout}"
                                       + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count()},
