@@ -79,15 +79,12 @@ def pmc_traffic(cls):
         data = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
     except Exception:
         return None
-    if "resident" in cls:
-        pref = ("tlin_res16_kernel", "tlin_res_kernel")
-    elif "stream" in cls:
-        pref = ("tlin_str_kernel",)
-    else:
-        pref = (cls.split("<")[0],)
+    # classes carry the kernels' own names: a full template name matches that instantiation, a bare name all of them
+    want = cls.replace(" ", "")
     n = b = 0.0
     for k, v in data.items():
-        if k.startswith(pref):
+        kk = k.replace(" ", "").replace("gg::", "")
+        if kk == want or ("<" not in want and kk.split("<")[0] == want):
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
     return round(b / n) if n else None
@@ -290,9 +287,12 @@ def main():
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
                                "share_of_step": round(dom["ms"] / (dt * 1e3 * prof_steps / args.steps), 3),
                                "timed_steps_with_events": prof_steps,
-                               "note": "live over the timed region, where the kernel shares the chip with the parameter-gradient / "
-                                       "prefetch kernels of the engine's side streams; `isolated` is the same kernel class with the "
-                                       "streams serialised (untimed warm-up step)",
+                               "note": "the kernel instantiation with the largest total time in a step with the engine's streams serialised "
+                                       "(classes carry the kernels' own template names, as rocprofv3 prints them); achieved / frac are "
+                                       "live over the timed region, where it shares the chip with the parameter-gradient / prefetch "
+                                       "kernels of the side streams; `isolated` is the same kernel in the serialised warm-up step. "
+                                       "In a rocprofv3 trace of the concurrent run the side-stream wgrad_kernel<true,false,false,false> "
+                                       "shows a larger total: its durations include waiting for compute units the main chain holds",
                                "isolated": iso,
                                "all_gemm_classes_note": "one untimed warm-up step with event pairs on every class" if rows_all else
                                                         "timed region",

@@ -177,6 +177,9 @@ struct gg_engine {
     size_t prof_next = 0;
     struct ProfAgg { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
     std::vector<ProfAgg> prof_agg;
+    int str_cls[16] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
+    int n_str_cls = 0;
+    std::string str_cls_name[14];
 };
 
 namespace {
@@ -441,7 +444,9 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
     if (e->wgrad_on && e->precision == GG_PREC_BF16 && wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K)) {
         e->launches++;
         gg_engine::ProfRec r;
-        const bool prof = e->prof_on && ((e->prof_mask >> 10) & 1u);
+        // classes follow the kernel instantiations: wgrad_kernel<dY bf16, X bf16, FiLM on the fly, FiLM gradient>
+        const int wcls = film ? 17 : (dy_bf16 ? (x_bf16 ? 15 : 10) : 16);
+        const bool prof = e->prof_on && ((e->prof_mask >> wcls) & 1u);
         if (prof) {
             if (e->prof_next + 2 > e->prof_pool.size()) {
                 for (int i = 0; i < 4096; ++i) {
@@ -450,7 +455,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
                     e->prof_pool.push_back(ev);
                 }
             }
-            r.cls = 10;
+            r.cls = wcls;
             r.flops = 2.0 * M * N * (double)K;
             r.bytes = (double)M * N * (dy_bf16 ? 2 : 4) + (double)M * K * (x_bf16 ? 2 : 4) + 4.0 * N * K;
             r.e0 = e->prof_pool[e->prof_next++];
@@ -497,7 +502,20 @@ inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    //
 int try_tlin(Ctx& c, const TlinP& p) {
     if (!use_tlin(c.e) || !tlin_supported(p)) return 0;
     c.e->launches++;
-    const int tcls = 8 + ((p.ln_g || p.res || p.K > 256) ? 1 : 0);
+    static const int tlin_cls[5] = {8, 9, 12, 13, 14};
+    const int kc = tlin_kernel_class(p);
+    int tcls = kc < 16 ? tlin_cls[kc] : 8;
+    if (kc >= 16) {     // stream instantiations get a class each, in order of first appearance (ids 18..31)
+        gg_engine* e = c.e;
+        int& id = e->str_cls[kc - 16];
+        if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
+            id = 18 + e->n_str_cls++;
+            char nm[64];
+            snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
+            e->str_cls_name[id - 18] = nm;
+        }
+        if (id) tcls = id;
+    }
     if (c.e->prof_on && ((c.e->prof_mask >> tcls) & 1u)) {
         gg_engine* e = c.e;
         if (e->prof_next + 2 > e->prof_pool.size()) {
@@ -508,7 +526,7 @@ int try_tlin(Ctx& c, const TlinP& p) {
             }
         }
         gg_engine::ProfRec r;
-        r.cls = 8 + ((p.ln_g || p.res || p.K > 256) ? 1 : 0);
+        r.cls = tcls;
         r.flops = 2.0 * p.M * p.N * (double)p.K;
         // algorithmic bytes at the element sizes actually stored: X once, Y once (+ LayerNorm output), residual,
         // previous Y when accumulating, sign-mask reference, bf16 weights once
@@ -519,9 +537,8 @@ int try_tlin(Ctx& c, const TlinP& p) {
                   2.0 * p.N * p.K;
         r.e0 = e->prof_pool[e->prof_next++];
         r.e1 = e->prof_pool[e->prof_next++];
-        if (hipEventRecord(r.e0, c.st) != hipSuccess) return -1;
+        tlin_time_next(r.e0, r.e1);           // dispatch timestamps of the kernel itself (what rocprofv3 reports), no barrier packets
         if (tlin(p, c.st) != 0) return -1;
-        if (hipEventRecord(r.e1, c.st) != hipSuccess) return -1;
         e->prof_recs.push_back(r);
         return 1;
     }
@@ -1619,12 +1636,19 @@ int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
     static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                                    "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
-    e->prof_agg.assign(12, gg_engine::ProfAgg());
+    e->prof_agg.assign(18 + e->n_str_cls, gg_engine::ProfAgg());
+    for (int i = 0; i < e->n_str_cls; ++i) e->prof_agg[18 + i].name = e->str_cls_name[i];
+    e->prof_agg[15].name = "wgrad_kernel<true,true,false,false>";
+    e->prof_agg[16].name = "wgrad_kernel<false,false,false,false>";
+    e->prof_agg[17].name = "wgrad_kernel<false,false,true,false>";
+    e->prof_agg[12].name = "tlin_res16_kernel<8,256,true,1>";      // + residual + LayerNorm epilogue
+    e->prof_agg[13].name = "tlin_res16_kernel<8,256,true,2>";      // += (data gradients)
+    e->prof_agg[14].name = "tlin_res16_kernel<8,256,true,0|3>";
     e->prof_agg[11].name = "gemm_small_kernel";
-    e->prof_agg[10].name = "wgrad_kernel";
+    e->prof_agg[10].name = "wgrad_kernel<true,false,false,false>";
     for (int i = 0; i < 8; ++i) e->prof_agg[i].name = names[i];
-    e->prof_agg[8].name = "tlin_kernel<64,stream>";
-    e->prof_agg[9].name = "tlin_kernel<32,resident>";
+    e->prof_agg[8].name = "tlin_str_kernel";
+    e->prof_agg[9].name = "tlin_res_kernel";
     for (auto& r : e->prof_recs) {
         if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("hipEventSynchronize failed"); return -1; }
         float ms = 0.f;

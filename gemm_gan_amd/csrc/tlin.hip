@@ -20,11 +20,24 @@
 #include "kernels.h"
 #include "drop_rng.h"
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace gg {
 
 namespace {
+// Optional dispatch timestamps for the next launch (tlin_time_next): hipExtLaunchKernelGGL stamps the two events at the
+// kernel's own begin / end, like a profiler, instead of bracketing it with barrier packets on the stream.
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+template <typename K>
+inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t st, const TlinP& p) {
+    if (g_ev0) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)smem, st, g_ev0, g_ev1, 0, p);
+        g_ev0 = g_ev1 = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, smem, st, p);
+    }
+}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -714,7 +727,7 @@ int launch_res(const TlinP& p, hipStream_t st) {
         attr_set = true;
     }
     const long blocks = (p.M + 127) / 128;
-    hipLaunchKernelGGL((tlin_res_kernel<NT_RES, KSL, XB, PRE>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    launch_timed(tlin_res_kernel<NT_RES, KSL, XB, PRE>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -727,7 +740,7 @@ int launch_res16(const TlinP& p, hipStream_t st) {
         attr_set = true;
     }
     const long blocks = (p.M + 63) / 64;
-    hipLaunchKernelGGL((tlin_res16_kernel<NT_RES, KSL, XB, PRE>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    launch_timed(tlin_res16_kernel<NT_RES, KSL, XB, PRE>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -742,7 +755,7 @@ int launch_str(const TlinP& p, hipStream_t st) {
         attr_set = true;
     }
     const long blocks = (p.M + 127) / 128;
-    hipLaunchKernelGGL((tlin_str_kernel<KSL, XB, YB, EPI>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    launch_timed(tlin_str_kernel<KSL, XB, YB, EPI>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -799,6 +812,27 @@ bool tlin_supported(const TlinP& p) {
     if (p.N == 64) return p.K % 64 == 0;
     return false;
 }
+
+// which kernel tlin() launches for p (profiling classes follow the kernels' own names): 0 tlin_str_kernel, 1 tlin_res_kernel
+// (32-token waves), 2 tlin_res16_kernel<..., PRE_RES> (+ residual + LayerNorm), 3 <..., PRE_ACC> (+=), 4 other res16 modes
+int tlin_kernel_class(const TlinP& p) {
+    if (!needs_resident(p)) {
+        if (p.K != 256) return 0;
+        // 16 + the <XB, YB, EPI> instantiation launch_str_256 picks: bit 0 XB, bit 1 YB, bits 2..3 EPI
+        int epi = EPI_BIAS;
+        if (p.accumulate || (p.mask_ref && p.drop.p > 0.f)) epi = EPI_ANY;
+        else if (p.mask_ref) epi = EPI_MASK;
+        else if (p.drop.p > 0.f) epi = EPI_DROP;
+        return 16 + (p.x_bf16 ? 1 : 0) + (p.y_bf16 ? 2 : 0) + 4 * epi;
+    }
+    static const bool v32 = getenv("GG_TLIN_RES32") != nullptr;
+    if (p.N != 256 || !p.x_bf16 || v32) return 1;
+    if (p.res && !p.accumulate) return 2;
+    if (p.accumulate && !p.res) return 3;
+    return 4;
+}
+
+void tlin_time_next(hipEvent_t begin, hipEvent_t end) { g_ev0 = begin; g_ev1 = end; }
 
 int tlin(const TlinP& p_in, hipStream_t st) {
     GG_REQUIRE(tlin_supported(p_in), "tlin: unsupported shape / alignment");

@@ -199,15 +199,19 @@ class Engine:
 
     PROFILE_CLASSES = ["gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                        "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>",
-                       "tlin_kernel<64,stream>", "tlin_kernel<32,resident>", "wgrad_kernel", "gemm_small_kernel"]
+                       "tlin_str_kernel", "tlin_res_kernel", "wgrad_kernel<true,false,false,false>", "gemm_small_kernel",
+                       "tlin_res16_kernel<8,256,true,1>", "tlin_res16_kernel<8,256,true,2>", "tlin_res16_kernel<8,256,true,0|3>",
+                       "wgrad_kernel<true,true,false,false>", "wgrad_kernel<false,false,false,false>",
+                       "wgrad_kernel<false,false,true,false>"]
 
     def profile(self, on: bool, classes=None):
         """HIP-event pair around every GEMM-class launch (classes=None) or only around the named classes."""
         arg = int(bool(on))
         if on and classes:
             mask = 0
+            ids = getattr(self, "_prof_ids", {})         # names seen by the last profile_collect (stream-Linear classes are dynamic)
             for c in classes:
-                mask |= 1 << self.PROFILE_CLASSES.index(c)
+                mask |= 1 << (ids[c] if c in ids else self.PROFILE_CLASSES.index(c))
             arg = 1 | (mask << 1)
         L.check(self.lib.gg_profile_enable(self.h, arg))
 
@@ -222,11 +226,13 @@ class Engine:
         if n < 0:
             L.check(n)
         rows = []
+        self._prof_ids = {}
         for i in range(n):
             name = C.create_string_buffer(128)
             launches, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             L.check(self.lib.gg_profile_read(self.h, i, name, 128, C.byref(launches), C.byref(ms), C.byref(fl), C.byref(by)))
             rows.append(dict(name=name.value.decode(), launches=launches.value, ms=ms.value, flops=fl.value, bytes=by.value))
+            self._prof_ids[rows[-1]["name"]] = i
         return rows
 
     def launch_count(self):
