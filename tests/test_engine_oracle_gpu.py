@@ -488,7 +488,8 @@ def test_side_streams_do_not_change_results(case):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256"])
+@pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256", "film_P1",
+                                  "film_P33_E256"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""
