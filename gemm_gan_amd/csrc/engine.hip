@@ -38,7 +38,7 @@ struct Net {
     int role = 0;
     std::vector<ParamInfo> ps;
     long total = 0;
-    long cls, film_w, film_b, te_w, te_b, pe_w, pe_b;
+    long cls, film_w, film_b, te_w, te_b, pe_w, pe_b, pe_lnw = 0, pe_lnb = 0;
     LayerP layer[MAXL];
     AttnP t2i, i2t;
     long w1, b1, w2, b2, w3, b3;
@@ -83,6 +83,7 @@ struct CondActs {
     bool flash = false;
     bool bst = false;          // qkv / ctx / h (and their gradients) stored as bf16 in this pass
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
+    float *pe_h = nullptr, *pe_y = nullptr, *pe_st = nullptr, *pe_zero = nullptr;     // Linear->ReLU->LayerNorm patch encoder (img variant)
     uint8_t* mask;
     LayerActs L[MAXL];
     float *t2i_q, *t2i_kv, *t2i_P, *t2i_ctx, *t2i_out, *t2i_xbar, *t2i_qt;
@@ -125,6 +126,8 @@ struct gg_engine {
     int precision = GG_PREC_F32;
     bool xattn = true;         // text<->image cross attention (conditional_gan_cross_attention_with_film.py); false: CLS row (conditional_gan_film.py)
     bool enc_bias = true;      // encoder layers with biases (bias=False in conditional_gan_film.py:115)
+    bool film = true;          // FiLM modulation of the patches from the text vector; false: conditional_gan_img_transformer.py
+    bool pe_ln = false;        // patch encoder = Linear -> ReLU -> LayerNorm (conditional_gan_img_transformer.py:106-110)
     uint64_t seed = 0;
     uint32_t call_counter = 0;
     int64_t launches = 0;
@@ -197,14 +200,23 @@ void build_net(gg_engine* e, int role) {
     // visible parameters first, ghosts (see Net::add_ghost) behind them
     const bool xa = e->xattn, eb = e->enc_bias;
     n.cls = n.add("patches_cls_token", 1, 1, E);
-    n.film_w = n.add("film_generator.weight", 2 * Dp, Dt);
-    n.film_b = n.add("film_generator.bias", 2 * Dp);
+    if (e->film) {
+        n.film_w = n.add("film_generator.weight", 2 * Dp, Dt);
+        n.film_b = n.add("film_generator.bias", 2 * Dp);
+    }
     if (xa) {
         n.te_w = n.add("text_encoder.weight", E, Dt);
         n.te_b = n.add("text_encoder.bias", E);
     }
-    n.pe_w = n.add("patches_encoder.weight", E, Dp);
-    n.pe_b = n.add("patches_encoder.bias", E);
+    if (e->pe_ln) {     // nn.Sequential(Linear, ReLU, LayerNorm): modules 0 and 2 carry parameters
+        n.pe_w = n.add("patches_encoder.0.weight", E, Dp);
+        n.pe_b = n.add("patches_encoder.0.bias", E);
+        n.pe_lnw = n.add("patches_encoder.2.weight", E);
+        n.pe_lnb = n.add("patches_encoder.2.bias", E);
+    } else {
+        n.pe_w = n.add("patches_encoder.weight", E, Dp);
+        n.pe_b = n.add("patches_encoder.bias", E);
+    }
     for (int l = 0; l < e->nl; ++l) {
         const std::string p = "patches_transformer.layers." + std::to_string(l) + ".";
         LayerP& L = n.layer[l];
@@ -245,6 +257,7 @@ void build_net(gg_engine* e, int role) {
             L.n1b = n.add_ghost(E); L.n2b = n.add_ghost(E);
         }
     }
+    if (!e->film) n.film_w = n.film_b = n.add_ghost(8);
     if (!xa) {      // never read: the offsets only have to be valid
         n.te_w = n.te_b = n.add_ghost(8);
         n.t2i.inw = n.t2i.inb = n.t2i.ow = n.t2i.ob = n.te_w;
@@ -268,6 +281,12 @@ void carve_cond(gg_engine* e, Arena& a, CondActs& c, int R) {
     c.xrep = a.take<float>(RB * S * E);
     c.tokrep = a.take<float>(RB * T * E);
     c.mask = a.take<uint8_t>(B * S);
+    if (e->pe_ln) {
+        c.pe_h = a.take<float>(B * S * E);
+        c.pe_y = a.take<float>(B * S * E);
+        c.pe_st = a.take<float>(B * S * 2);
+        c.pe_zero = a.take<float>(E);
+    }
     for (int l = 0; l < e->nl; ++l) {
         LayerActs& L = c.L[l];
         L.qkv = a.take<float>(RB * S * 3 * E);
@@ -575,8 +594,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     a.B = B; a.R = R; a.P = P; a.T = T; a.drop = drop; a.call = ++e->call_counter;
     const float* w = n.w;
     // FiLM parameters from the text CLS token (row b of `text` viewed with ld = T*Dt)
-    GG_TRY(lin_fwd(c, in->text, (long)T * Dt, w + n.film_w, Dt, w + n.film_b, a.gbpre, 2 * Dp, B, 2 * Dp, Dt));
-    KL(k_film_act_fwd(a.gbpre, a.gb, B, Dp, c.st));
+    if (e->film) {
+        GG_TRY(lin_fwd(c, in->text, (long)T * Dt, w + n.film_w, Dt, w + n.film_b, a.gbpre, 2 * Dp, B, 2 * Dp, Dt));
+        KL(k_film_act_fwd(a.gbpre, a.gb, B, Dp, c.st));
+    }
     // text encoder
     if (!e->xattn) {
         // FiLM-only variant: no token encoder, no cross attention (conditional_gan_film.py:130-152)
@@ -588,6 +609,18 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     } else {
         GG_TRY(lin_fwd(c, in->text, Dt, w + n.te_w, Dt, w + n.te_b, a.tok, E, B * T, E, Dt));
     }
+    if (e->pe_ln) {
+        // conditional_gan_img_transformer.py:106-110,126: Linear -> ReLU -> LayerNorm on the raw patches (no FiLM); the
+        // ReLU output (LayerNorm's input) and the row statistics are kept for the backward
+        TlinP t;
+        t.X = in->patches; t.ldx = Dp; t.M = (long)B * P; t.W = WB(n, n.pe_w); t.ldw = Dp; t.bias = w + n.pe_b;
+        t.Y = a.pe_h; t.ldy = E; t.N = E; t.K = Dp;
+        TLIN_OR(t, GG_TRY(lin_fwd(c, in->patches, Dp, w + n.pe_w, Dp, w + n.pe_b, a.pe_h, E, B * P, E, Dp)));
+        KL(k_bias_act(a.pe_h, nullptr, (long)B * P, E, ACT_LRELU, 0.f, c.st));
+        KL(k_fill(a.pe_zero, E, 0.f, c.st));
+        KL(k_add_layernorm_fwd(a.pe_zero, 1, a.pe_h, w + n.pe_lnw, w + n.pe_lnb, a.pe_y, a.pe_st, (long)B * P, E, DropKey(), c.st));
+        KL(k_scatter_patch_rows(a.x0, a.pe_y, B, P, E, c.st));
+    } else
     // patch encoder with FiLM fused on the A operand; rows land behind the CLS row of each sample
     {
         TlinP t;
@@ -1053,6 +1086,17 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     if (i2t_sh) KL(k_fold_rows_add(e->s_dtokrep, (long)T * E, e->s_dtok0, B, Rb, E, c.st));      // + the T2I query rows (token 0)
     KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
     KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
+    if (e->pe_ln) {
+        // Linear -> ReLU -> LayerNorm patch encoder, no FiLM: LayerNorm backward on the saved ReLU output, ReLU mask from the
+        // same tensor (h > 0), then the plain weight / bias gradients against the raw patches
+        KL(k_layernorm_bwd(e->s_demb, a.pe_h, a.pe_st, w + n.pe_lnw, e->s_dx0 /* scratch: dx0 is consumed */, nullptr, g + n.pe_lnw,
+                           g + n.pe_lnb, nullptr, (long)B * P, E, DropKey(), c.st));
+        KL(k_act_bwd(e->s_dx0, a.pe_h, (long)B * P * E, 0.f, 1.f, c.st));
+        GG_TRY(lin_bwd_weight(c, e->s_dx0, E, in->patches, Dp, g + n.pe_w, Dp, B * P, E, Dp));
+        KL(k_colsum(e->s_dx0, (long)B * P, E, E, g + n.pe_b, c.st));
+        for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));
+        return 0;
+    }
     if (wgrad_film_ok(e, e->s_demb, E, in->patches, Dp, B * P, E, Dp, P)) {
         // dW_pe += demb^T (gamma * patches + beta): the modulation is applied while the token chunks are staged
         WgradFilm f;
@@ -1404,8 +1448,11 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->cfg = *cfg;
     e->E = cfg->embedding_dims; e->F = 2 * e->E; e->H = cfg->hidden_dims; e->G = cfg->n_genes; e->L = cfg->latent_dims;
     e->Dt = cfg->text_dims; e->Dp = cfg->patch_dims; e->nh = cfg->n_heads; e->nl = cfg->n_layers; e->dh = e->E / e->nh;
-    e->xattn = cfg->variant != GG_VARIANT_FILM;
-    e->enc_bias = cfg->variant != GG_VARIANT_FILM;
+    GG_REQUIRE(cfg->variant >= GG_VARIANT_XATTN_FILM && cfg->variant <= GG_VARIANT_IMG, "unknown variant");
+    e->xattn = cfg->variant == GG_VARIANT_XATTN_FILM;
+    e->enc_bias = cfg->variant == GG_VARIANT_XATTN_FILM;
+    e->film = cfg->variant != GG_VARIANT_IMG;
+    e->pe_ln = cfg->variant == GG_VARIANT_IMG;
     e->maxB = cfg->max_batch; e->maxP = cfg->max_patches; e->maxT = cfg->max_text_tokens; e->maxS = e->maxP + 1;
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
     e->dropout = cfg->dropout;

@@ -91,6 +91,8 @@ int k_fold_rows_add(float* dst, long ldd, const float* src, long B, int R, int c
 int k_fold(float* out, const float* in, long n, int R, hipStream_t st);
 // out[(b*P+p), :] = seq[b, 1+p, :]   (drop the CLS row: [B,P+1,E] -> [B*P,E])
 int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st);
+// the inverse: seq[b, 1+p, :] = in[(b*P+p), :]
+int k_scatter_patch_rows(float* seq, const float* in, int B, int P, int E, hipStream_t st);
 // out = in * keep/(1-p)   (re-materialise dropped attention probabilities in backward)
 int k_dropout_copy(float* out, const float* in, long n, DropKey drop, hipStream_t st);
 

@@ -1032,6 +1032,19 @@ __global__ void gather_patch_rows_k(float* out, const float* seq, int B, int P, 
         out[i] = seq[(row + b + 1) * E + e];
     }
 }
+__global__ void scatter_patch_rows_k(float* seq, const float* in, int B, int P, int E) {
+    const long n = (long)B * P * E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / E;
+        const int e = (int)(i - row * E);
+        const long b = row / P;
+        seq[(row + b + 1) * E + e] = in[i];
+    }
+}
+int k_scatter_patch_rows(float* seq, const float* in, int B, int P, int E, hipStream_t st) {
+    scatter_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(seq, in, B, P, E);
+    GG_LAUNCH_CHECK();
+}
 int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st) {
     gather_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(out, seq, B, P, E);
     GG_LAUNCH_CHECK();

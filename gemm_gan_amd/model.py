@@ -55,11 +55,17 @@ class _CondNet(nn.Module):
         self.is_bn = is_bn
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         # construction order == reference order (R:111-126), so a given torch seed gives the same init
-        film_only = self._variant == "film"      # src/conditional_gan_film.py:111-124: no token encoder / cross attention
-        self.film_generator = nn.Linear(text_embedding_dims, patches_embedding_dims * 2)
+        # src/conditional_gan_film.py:111-124 and src/conditional_gan_img_transformer.py:105-117: no token encoder / cross
+        # attention, bias-free encoder layers; the image-transformer file has no FiLM and a Linear-ReLU-LayerNorm patch encoder
+        film_only = self._variant in ("film", "img")
+        if self._variant != "img":
+            self.film_generator = nn.Linear(text_embedding_dims, patches_embedding_dims * 2)
         if not film_only:
             self.text_encoder = nn.Linear(text_embedding_dims, E)
-        self.patches_encoder = nn.Linear(patches_embedding_dims, E)
+        if self._variant == "img":
+            self.patches_encoder = nn.Sequential(nn.Linear(patches_embedding_dims, E), nn.ReLU(), nn.LayerNorm(E))
+        else:
+            self.patches_encoder = nn.Linear(patches_embedding_dims, E)
         self.patches_transformer_layer = nn.TransformerEncoderLayer(
             d_model=E, nhead=4, dim_feedforward=E * 2, dropout=0.1, activation="relu", batch_first=True,
             bias=not film_only)

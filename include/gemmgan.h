@@ -51,6 +51,9 @@ extern "C" {
 #define GG_VARIANT_FILM 1       /* src/conditional_gan_film.py:97-205: FiLM + bias-free encoder (R':115 bias=False), the   */
                                 /* conditioning vector is the encoder's CLS row (R':150); text is one vector per sample (T=1) */
 
+#define GG_VARIANT_IMG 2        /* src/conditional_gan_img_transformer.py:95-190: no FiLM, patch encoder Linear -> ReLU ->  */
+                                /* LayerNorm (R'':106-110), bias-free encoder, CLS-row conditioning; text is unused         */
+
 typedef struct gg_config {
     /* model shape: WGAN_GP.__init__ kwargs R:258-271, generator/discriminator ctors R:99, R:169 */
     int32_t n_genes;        /* input_dims / vector_dims (G)                           */

@@ -189,7 +189,8 @@ def stage_hooks(net, role, taps):
         def fn(_m, _i, o):
             taps[name] = pick(o).detach().clone()
         return fn
-    hs.append(net.film_generator.register_forward_hook(tap("film_pre")))
+    if hasattr(net, "film_generator"):
+        hs.append(net.film_generator.register_forward_hook(tap("film_pre")))
     if hasattr(net, "text_encoder"):
         hs.append(net.text_encoder.register_forward_hook(tap("text_enc")))
     hs.append(net.patches_encoder.register_forward_hook(tap("patch_emb")))
@@ -210,7 +211,7 @@ def make_fixture(ref, name, dims, seed):
     out["dims"] = np.array([dims[k] for k in ("B", "G", "P", "T", "Dt", "Dp", "E", "H", "L", "n_critic")],
                            dtype=np.int64)
     out["slope"] = np.float32(dims.get("slope", 0.0))
-    film = dims.get("variant", "xattn_film") == "film"
+    film = dims.get("variant", "xattn_film") in ("film", "img")      # the 4-argument files
     out["variant"] = np.array(dims.get("variant", "xattn_film"))
     call = Calls(film)
     torch.manual_seed(seed)
@@ -292,7 +293,8 @@ def make_fixture(ref, name, dims, seed):
     sd_to_np("gen1/post_gen", w2.gen.state_dict(), out, stride=3)
 
     # ---- full train() (:463-477) for the three optimisers
-    for opt in ("rms_prop", "adam", "adamw"):
+    # conditional_gan_img_transformer.py:277-286 knows rms_prop and adam only
+    for opt in (("rms_prop", "adam") if dims.get("variant") == "img" else ("rms_prop", "adam", "adamw")):
         w = build(ref, dims, opt, init)
         torch.manual_seed(seed + 5)
         with Recorder() as rec:
@@ -323,7 +325,11 @@ FIXTURES = {
     # FiLM-only sibling (src/conditional_gan_film.py; BASELINE configs[1]: one patch, text vector)
     "film_P1": dict(B=6, G=41, P=1, T=1, Dt=20, Dp=28, E=32, H=24, L=12, n_critic=5, variant="film"),
     "film_P7": dict(B=4, G=33, P=7, T=1, Dt=16, Dp=24, E=32, H=16, L=8, n_critic=2, variant="film", slope=0.1),
+    # image-transformer sibling (src/conditional_gan_img_transformer.py; BASELINE configs[4] family)
+    "img_P9": dict(B=5, G=45, P=9, T=1, Dt=12, Dp=28, E=32, H=24, L=10, n_critic=3, variant="img"),
 }
+REF_MODULE = {"xattn_film": "conditional_gan_cross_attention_with_film", "film": "conditional_gan_film",
+              "img": "conditional_gan_img_transformer"}
 
 
 def main():
@@ -332,8 +338,7 @@ def main():
     for i, (name, dims) in enumerate(FIXTURES.items()):
         if only and name not in only:
             continue
-        film = dims.get("variant") == "film"
-        ref = import_reference("conditional_gan_film" if film else "conditional_gan_cross_attention_with_film")
+        ref = import_reference(REF_MODULE[dims.get("variant", "xattn_film")])
         make_fixture(ref, name, dims, seed=1234 + 100 * i)
 
 

@@ -57,6 +57,8 @@ class PathConfig:
     # "film": src/conditional_gan_film.py - no token encoder / cross attention, the conditioning vector is the encoder's
     # CLS row (F:150), bias-free encoder layers (F:115 bias=False), no gradient clipping (F:383-385): use
     # film_config() so the clip fields follow
+    # "img": src/conditional_gan_img_transformer.py (I:95-190) - like "film" but without FiLM: the patch encoder is
+    # Linear -> ReLU -> LayerNorm on the raw patches (I:106-110), the text input is unused
     variant: str = "xattn_film"
 
     @property
@@ -69,6 +71,13 @@ def film_config(**kw) -> PathConfig:
     kw.setdefault("clip_d", None)
     kw.setdefault("clip_g", None)
     return PathConfig(variant="film", **kw)
+
+
+def img_config(**kw) -> PathConfig:
+    """PathConfig of the image-transformer sibling (src/conditional_gan_img_transformer.py): no FiLM, no clipping."""
+    kw.setdefault("clip_d", None)
+    kw.setdefault("clip_g", None)
+    return PathConfig(variant="img", **kw)
 
 
 def _mlp_block(n_in: int, n_out: int, slope: float) -> nn.Sequential:
@@ -88,12 +97,16 @@ class CondNet(nn.Module):
         assert role in ("generator", "discriminator")
         self.role, self.cfg = role, cfg
         E, Dt, Dp = cfg.embedding_dims, cfg.text_dims, cfg.patch_dims
-        film_only = cfg.variant == "film"
-        assert cfg.variant in ("xattn_film", "film")
-        self.film_generator = nn.Linear(Dt, 2 * Dp)
+        film_only = cfg.variant in ("film", "img")       # no token encoder / cross attention, bias-free encoder
+        assert cfg.variant in ("xattn_film", "film", "img")
+        if cfg.variant != "img":
+            self.film_generator = nn.Linear(Dt, 2 * Dp)
         if not film_only:
             self.text_encoder = nn.Linear(Dt, E)
-        self.patches_encoder = nn.Linear(Dp, E)
+        if cfg.variant == "img":                          # I:106-110
+            self.patches_encoder = nn.Sequential(nn.Linear(Dp, E), nn.ReLU(), nn.LayerNorm(E))
+        else:
+            self.patches_encoder = nn.Linear(Dp, E)
         self.patches_transformer_layer = nn.TransformerEncoderLayer(
             d_model=E, nhead=cfg.n_heads, dim_feedforward=cfg.ffn_dims, dropout=cfg.dropout,
             activation="relu", batch_first=True, bias=not film_only)      # F:113-115: bias=False
@@ -114,16 +127,20 @@ class CondNet(nn.Module):
     # -- conditioning stack shared by both roles (:129-155 == :198-224) ------------------------
     def conditioning(self, patches, patch_pad, text, text_pad, taps: Optional[dict] = None):
         Dp = self.cfg.patch_dims
-        gb = self.film_generator(text[:, 0, :])
-        gamma = torch.tanh(gb[:, :Dp])
-        beta = torch.clamp(gb[:, Dp:], min=-5.0, max=5.0)
-        mod = gamma[:, None, :] * patches + beta[:, None, :]
-        emb = self.patches_encoder(mod)
+        if self.cfg.variant == "img":                     # I:126: the encoder sees the raw patches; text is unused
+            gamma = beta = None
+            emb = self.patches_encoder(patches)
+        else:
+            gb = self.film_generator(text[:, 0, :])
+            gamma = torch.tanh(gb[:, :Dp])
+            beta = torch.clamp(gb[:, Dp:], min=-5.0, max=5.0)
+            mod = gamma[:, None, :] * patches + beta[:, None, :]
+            emb = self.patches_encoder(mod)
         B = emb.shape[0]
         seq = torch.cat((self.patches_cls_token.expand(B, -1, -1), emb), dim=1)
         mask = torch.cat((patch_pad.new_zeros(B, 1, dtype=torch.bool), patch_pad), dim=1)
         enc = self.patches_transformer(seq, src_key_padding_mask=mask)
-        if self.cfg.variant == "film":      # F:130-152: text is one vector per sample (here [B,1,Dt]); c = CLS row
+        if self.cfg.variant in ("film", "img"):      # F:130-152 / I:124-136: text is one vector per sample (here [B,1,Dt]); c = CLS row
             c = enc[:, 0, :]
             if taps is not None:
                 taps.update(gamma=gamma, beta=beta, seq0=seq, enc=enc, cond=c)

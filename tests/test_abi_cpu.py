@@ -90,7 +90,7 @@ def test_facade_state_dict_matches_reference_keys(name):
     import gemm_gan_amd as gga
     g = Golden(name)
     d = g.dims
-    mod = gga.film if g.variant == "film" else gga        # the mirror module of the reference file the fixture came from
+    mod = {"film": gga.film, "img": gga.img_transformer}.get(g.variant, gga)   # the mirror module of the fixture's reference file
     gen, disc = mod.WGAN_GP_model(d["L"], d["G"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1],
                                   d["Dt"], d["Dp"], g.slope, False)
     for net, prefix in ((gen, "init_gen"), (disc, "init_disc")):
@@ -101,17 +101,17 @@ def test_facade_state_dict_matches_reference_keys(name):
             assert tuple(sd[k].shape) == tuple(ref[k].shape), k
         net.load_state_dict(g.state(prefix), strict=True)
     with pytest.raises(RuntimeError, match="not bound"):
-        disc(*[torch.zeros(1)] * (4 if g.variant == "film" else 5))
+        disc(*[torch.zeros(1)] * (5 if g.variant == "xattn_film" else 4))
 
 
-@pytest.mark.parametrize("idx", [0, 2])
+@pytest.mark.parametrize("idx", [0, 2, 4])
 def test_facade_same_seed_same_init_as_reference(idx):
     """Construction order mirrors the reference, so torch.manual_seed(s) reproduces its initialisation."""
     import gemm_gan_amd as gga
     g = Golden(FIXTURES[idx])
     d = g.dims
     torch.manual_seed(1234 + 100 * idx)          # the seed oracle/make_golden.py used for fixture idx
-    mod = gga.film if g.variant == "film" else gga
+    mod = {"film": gga.film, "img": gga.img_transformer}.get(g.variant, gga)
     gen, disc = mod.WGAN_GP_model(d["L"], d["G"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1],
                                   d["Dt"], d["Dp"], g.slope, False)
     for net, prefix in ((gen, "init_gen"), (disc, "init_disc")):

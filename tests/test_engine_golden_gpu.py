@@ -40,15 +40,16 @@ def test_forward_stages(name):
     out = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=True)
     ref = g.group("disc_fwd")
     B, P, S, E, Dp = d["B"], d["P"], d["P"] + 1, d["E"], d["Dp"]
-    gb = eng.debug_buffer("D.gb").view(B, 2 * Dp)
-    ck.check("film gamma", gb[:, :Dp], np.tanh(ref["film_pre"][:, :Dp]))
-    ck.check("film beta", gb[:, Dp:], np.clip(ref["film_pre"][:, Dp:], -5, 5))
-    if g.variant != "film":
+    if g.variant != "img":
+        gb = eng.debug_buffer("D.gb").view(B, 2 * Dp)
+        ck.check("film gamma", gb[:, :Dp], np.tanh(ref["film_pre"][:, :Dp]))
+        ck.check("film beta", gb[:, Dp:], np.clip(ref["film_pre"][:, Dp:], -5, 5))
+    if g.variant == "xattn_film":
         ck.check("text encoder", eng.debug_buffer("D.tok").view(B, d["T"], E), ref["text_enc"])
     ck.check("patch encoder (FiLM fused)", eng.debug_buffer("D.x0").view(B, S, E)[:, 1:], ref["patch_emb"])
     ck.check("encoder layer 0", eng.debug_buffer("D.L0.x2").view(B, S, E), ref["enc_layer0"])
     ck.check("encoder layer 1", eng.debug_buffer("D.L1.x2").view(B, S, E), ref["enc_layer1"])
-    if g.variant != "film":
+    if g.variant == "xattn_film":
         ck.check("T2I attention", eng.debug_buffer("D.t2i_out").view(B, E), ref["t2i"])
         ck.check("I2T attention", eng.debug_buffer("D.i2t_out").view(B, E), ref["i2t"])
     ck.check("critic score", out, ref["out"])
@@ -109,6 +110,8 @@ def test_generator_iteration(name):
 @pytest.mark.parametrize("opt", ["rms_prop", "adam", "adamw"])
 def test_full_train_step(name, opt):
     g = Golden(name)
+    if f"step_{opt}/z" not in g.z.files:
+        pytest.skip("the reference file of this fixture has no such optimiser branch")
     eng, x, text, text_pad, patches, patch_pad = make(g, opt)
     ck = Checker(f"golden full train() {name} {opt}", TOL)
     z_all = g.t(f"step_{opt}/z").cuda().contiguous()

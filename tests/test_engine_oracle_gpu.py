@@ -7,7 +7,7 @@ import torch
 
 from gemm_gan_amd import _lib as L
 from gpu_util import Checker, dev, engine_from_cfg, load_oracle_state
-from oracle.torch_oracle import PathConfig, Trainer, film_config, set_dropout, synthetic_batch
+from oracle.torch_oracle import PathConfig, Trainer, film_config, img_config, set_dropout, synthetic_batch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -28,6 +28,9 @@ CASES = {
                                     patch_dims=56, dropout=0.0), B=9, P=1, T=1),
     "film_P33_E256": dict(cfg=film_config(n_genes=90, latent_dims=24, embedding_dims=256, hidden_dims=64, text_dims=48,
                                           patch_dims=64, dropout=0.0), B=4, P=33, T=1),
+    # image-transformer sibling (src/conditional_gan_img_transformer.py): Linear-ReLU-LayerNorm patch encoder, no FiLM
+    "img_P40_E256": dict(cfg=img_config(n_genes=70, latent_dims=16, embedding_dims=256, hidden_dims=48, text_dims=20,
+                                        patch_dims=72, dropout=0.0), B=4, P=40, T=1),
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
@@ -83,7 +86,7 @@ def test_critic_and_generator_iteration_vs_autograd(case):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256"])
+@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256", "img_P40_E256"])
 def test_replica_stacked_passes_vs_autograd(case):
     """With dropout on, the three critic passes of an iteration run as replicas stacked on the batch axis (two of them
     carry gradient; shared layer inputs, shared text keys, replica-summed gradients).  A drop probability of 1e-7 keeps
@@ -489,7 +492,7 @@ def test_side_streams_do_not_change_results(case):
 
 
 @pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256", "film_P1",
-                                  "film_P33_E256"])
+                                  "film_P33_E256", "img_P40_E256"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""

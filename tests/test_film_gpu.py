@@ -5,19 +5,20 @@ import numpy as np
 import pytest
 import torch
 
-from gemm_gan_amd import film
+from gemm_gan_amd import film, img_transformer
 from golden_util import Golden
 from gpu_util import Checker
 
 pytestmark = pytest.mark.gpu
-FILM_FIXTURES = ["film_P1", "film_P7"]
+FILM_FIXTURES = ["film_P1", "film_P7", "img_P9"]      # the 4-argument sibling files: FiLM-only and image-transformer
 
 
 def build(g: Golden, opt="rms_prop", **kw):
     d = g.dims
-    w = film.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
-                     patches_embedding_dims=d["Dp"], negative_slope=g.slope, optimizer=opt, n_critic=d["n_critic"],
-                     dropout=0.0, device="cuda:0", **kw)
+    mod = img_transformer if g.variant == "img" else film
+    w = mod.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
+                    patches_embedding_dims=d["Dp"], negative_slope=g.slope, optimizer=opt, n_critic=d["n_critic"],
+                    dropout=0.0, device="cuda:0", **kw)
     w.build_WGAN_GP()
     w.init_train()
     return w

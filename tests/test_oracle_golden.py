@@ -25,7 +25,7 @@ def test_state_dict_keys_and_dead_layer(name):
     assert set(tr.gen.state_dict()) == set(g.group("init_gen"))
     assert set(tr.disc.state_dict()) == set(g.group("init_disc"))
     dead = [k for k in g.group("critic1/grad_none")]
-    n_dead = 6 if g.variant == "film" else 12       # the template layer of the bias-free encoder has weights only
+    n_dead = 12 if g.variant == "xattn_film" else 6       # the template layer of the bias-free encoder has weights only
     assert len(dead) == n_dead and all(k.startswith("patches_transformer_layer.") for k in dead)
     assert not any(n.startswith("patches_transformer_layer.") for n, _ in live_parameters(tr.disc))
 
@@ -41,11 +41,12 @@ def test_forward_stages(name):
         out = tr.disc(x, patches, patch_pad, text, text_pad, taps)
     ref = g.group("disc_fwd")
     Dp = g.dims["Dp"]
-    assert rel_err(taps["gamma"], np.tanh(ref["film_pre"][:, :Dp])) < TOL
-    assert rel_err(taps["beta"], np.clip(ref["film_pre"][:, Dp:], -5, 5)) < TOL
+    if g.variant != "img":
+        assert rel_err(taps["gamma"], np.tanh(ref["film_pre"][:, :Dp])) < TOL
+        assert rel_err(taps["beta"], np.clip(ref["film_pre"][:, Dp:], -5, 5)) < TOL
     assert rel_err(taps["seq0"][:, 1:], ref["patch_emb"]) < TOL
     assert rel_err(taps["enc"], ref["enc_layer1"]) < TOL
-    if g.variant != "film":
+    if g.variant == "xattn_film":
         assert rel_err(taps["text_enc"], ref["text_enc"]) < TOL
         assert rel_err(taps["t2i"], ref["t2i"]) < TOL
         assert rel_err(taps["i2t"], ref["i2t"]) < TOL
@@ -69,7 +70,7 @@ def test_critic_iteration(name):
     los = g.z["critic1/losses"]
     assert rel_err([r["total"].item(), r["d_loss"].item(), r["d_real"].item(), r["d_fake"].item()], los) < TOL
     assert rel_err(r["grad_x_hat"].detach(), g.z["critic1/grad_x_hat"]) < TOL
-    if g.variant != "film":     # the FiLM-only file does not clip
+    if g.variant == "xattn_film":     # the sibling files do not clip
         assert abs(float(r["grad_norm_total"]) - float(g.z["critic1/grad_total_norm"])) < 1e-5 * float(g.z["critic1/grad_total_norm"])
     else:
         assert "grad_norm_total" not in r
@@ -99,6 +100,8 @@ def test_generator_iteration(name):
 @pytest.mark.parametrize("opt", ["rms_prop", "adam", "adamw"])
 def test_full_train_step(name, opt):
     g = Golden(name)
+    if f"step_{opt}/z" not in g.z.files:
+        pytest.skip("the reference file of this fixture has no such optimiser branch")
     tr = g.trainer(opt)
     x, text, text_pad, patches, patch_pad = g.inputs()
     zs = list(g.t(f"step_{opt}/z"))
