@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--text-dims", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--variant", choices=["xattn_film", "film"], default="xattn_film",
+    ap.add_argument("--variant", choices=["xattn_film", "film", "img"], default="xattn_film",
                     help="xattn_film: the headline path (conditional_gan_cross_attention_with_film.py); film: the FiLM-only "
-                         "sibling (conditional_gan_film.py; BASELINE configs[1] is --variant film --patches 1)")
+                         "sibling (conditional_gan_film.py; BASELINE configs[1] is --variant film --patches 1); img: "
+                         "conditional_gan_img_transformer.py (configs[4] per rank: --variant img --batch 128 --genes 18000 --patches 1024)")
     ap.add_argument("--pad-frac", type=float, default=0.0,
                     help="fraction of samples whose last P/4 patch tokens are padded (SURVEY 8d masking run: 0.25)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="bf16",
@@ -97,10 +98,10 @@ def log(msg):
 def cpu_baseline(args):
     """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
     bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 12 timed train() steps (about 20 s)."""
-    from oracle.torch_oracle import PathConfig, Trainer, film_config, synthetic_batch
+    from oracle.torch_oracle import PathConfig, Trainer, film_config, img_config, synthetic_batch
     cores = host_cores()
     torch.set_num_threads(cores)
-    make = film_config if args.variant == "film" else PathConfig
+    make = {"film": film_config, "img": img_config}.get(args.variant, PathConfig)
     cfg = make(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
     Bc = args.cpu_batch
     torch.manual_seed(42)
@@ -158,10 +159,11 @@ def main():
     G, B, P, T = args.genes, args.batch, args.patches, args.tokens
     H = E = Lz = 256
     torch.manual_seed(42)                       # identical initial weights on every rank
-    film = args.variant == "film"
+    film = args.variant in ("film", "img")          # the 4-argument reference files
     if film and T != 1:
-        raise SystemExit("--variant film takes one text vector per sample (--tokens 1)")
-    w = (gga.film.WGAN_GP if film else gga.WGAN_GP)(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
+        raise SystemExit("--variant film / img take one text vector per sample (--tokens 1)")
+    cls = {"film": gga.film.WGAN_GP, "img": gga.img_transformer.WGAN_GP}.get(args.variant, gga.WGAN_GP)
+    w = cls(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
                     optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="",
                     precision=args.precision)
     w.build_WGAN_GP()
@@ -250,7 +252,8 @@ def main():
         out = {"metric": "WGAN-GP samples/sec (n_critic=5, 5k-gene)", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": ("configs[1] family: conditional_gan_film.py train(), " if film else
+               "config": {"workload": ("configs[4] family: conditional_gan_img_transformer.py train(), " if args.variant == "img" else
+                                       "configs[1] family: conditional_gan_film.py train(), " if film else
                                        "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), ")
                                       + f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
                                       f"n_critic=5, rms_prop, dropout {args.dropout}"
