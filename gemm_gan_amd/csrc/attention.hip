@@ -342,6 +342,157 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// forward, long sequences (S above the LDS-resident range of attn_fwd_kernel, e.g. 1 025 patch tokens): grid.y splits
+// the query tiles four at a time (one per wave) and the keys stream through LDS in chunks of CK; the online softmax
+// state of a wave's query tile lives in registers across the chunks.  Same arithmetic and dropout stream as above.
+// ------------------------------------------------------------------------------------------------------
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                       int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
+                                                       int S, int E, int nh, DropKey drop, int qkv_B, int CK) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32;
+    constexpr int LDK = DH + 8;
+    const int LDV = CK + 8;                     // one chunk of CK keys (multiple of 32) is resident at a time
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vt = Ks + CK * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vt + DH * LDV);
+    constexpr int DT = (DH + 31) / 32;          // head-dim tiles of the O^T accumulator
+    constexpr int KS = DH / 16;                 // k-steps of the score product
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;      // this (sample, head) inside qkv; replicas may share one projection
+    for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
+    __syncthreads();
+    uint8_t* Mt = Ms + Sp;                                 // per key tile: does it hold any masked / padded key?
+    for (int t = tid; t < Sp / 32; t += 256) {
+        uint8_t any = 0;
+        for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
+        Mt[t] = any;
+    }
+    __syncthreads();
+
+    const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int nqt = Sp / 32;
+    // one query tile per wave: tile 4 * blockIdx.y + wave; waves past the end still take part in the staging barriers
+    const int qt = 4 * (int)blockIdx.y + wave;
+    const bool active = qt < nqt;
+    {
+        const int q = qt * 32 + c;
+        bf16x8 qf[KS];
+        const int qc = min(max(q, 0), S - 1);          // rows past the end re-read the last query: never stored
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+        float m = -INFINITY, l = 0.f;
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+        // dropout stream state of this lane's row at its first key pair (drop_rng.h: linear in the pair index)
+        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+        for (int kbase = 0; kbase < Sp; kbase += CK) {
+        const int krows = min(CK, Sp - kbase);             // staged rows of this chunk (multiple of 32)
+        __syncthreads();                                   // the previous chunk's readers are done (first pass: Mt is written)
+        stage_rows<DH, IOB>(Ks, qkv, base + E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), krows, tid, 256);
+        stage_transposed<DH, IOB>(Vt, qkv, base + 2 * E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), CK, tid, 256);
+        __syncthreads();
+        if (active)
+        for (int kl = 0; kl < krows / 32; ++kl) {
+            const int kt = kbase / 32 + kl;
+            f32x16 s16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s16[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kl * 32 + c) * LDK + 16 * s + 8 * h);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            } else {                    // tile without masked keys: no per-element mask lookups
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s16[i] *= sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            // Lazy reference update: the softmax reference m only moves when a tile's maximum exceeds it by more than
+            // 2^8 (scores are in the log2 domain), so p <= 256 in between - exact after the final O / l - and the
+            // O *= alpha pass over the 32 output accumulators is skipped for almost every tile.
+            const bool move = mt > m + 8.f;
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const float mn = move ? mt : m;
+                const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);      // mn is finite wherever move is set
+                l *= alpha;
+                m = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            }
+            const float mref = (m == -INFINITY) ? 0.f : m;
+            float lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = fast_exp2(s16[i] - mref);
+                lt += p;
+                s16[i] = p;
+            }
+            lt += __shfl_xor(lt, 32, 64);
+            l += lt;
+            if (drop.p > 0.f) {     // registers 4g..4g+3 hold 4 consecutive keys: two pair hashes
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    s16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? s16[4 * g + 0] : 0.f;
+                    s16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? s16[4 * g + 1] : 0.f;
+                    s16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? s16[4 * g + 2] : 0.f;
+                    s16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? s16[4 * g + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = frag_transposed(Vt, LDV, min(dt * 32 + c, DH - 1), kl * 32, s2, h);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[dt], 0, 0, 0);
+                }
+            }
+        }
+        }   // key chunks
+        if (active && q < S) {
+            const float inv = ks / l;
+            const long out = ((long)n * S + q) * E + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv};
+                        store4<IOB>(ctx, out + d, v);
+                    }
+                }
+            if (h == 0) lse2[(long)blockIdx.x * S + q] = m + log2f(l);
+        }
+    }
+}
+
 // delta[n,h,q] = sum_d dO[n,q,h*DH+d] * O[n,q,h*DH+d]
 __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta,
                                   long rows, int S, int E, int nh) {
@@ -723,6 +874,168 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const void* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, dQ, long sequences: attn_bwd_dq2_kernel's scheme with a run-time number of key chunks of CK keys and grid.y
+// over groups of 4 * DQ_SLOTS query tiles (no shared left-over tile: every tile belongs to one wave).
+// ------------------------------------------------------------------------------------------------------
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __restrict__ qkv, const void* __restrict__ ctx,
+                                                              const void* __restrict__ dctx,
+                                                              const float* __restrict__ lse2, float* __restrict__ delta,
+                                                              const uint8_t* __restrict__ mask, int mask_B,
+                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B, int CK) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const int ckt = CK / 32;                        // key tiles per chunk (CK keys, a multiple of 32, resident at a time)
+    const int nch = (nkt + ckt - 1) / ckt;
+    constexpr int LDK = DH + 8;
+    const int LDT = CK + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vs = Ks + CK * LDK;
+    __bf16* Kt = Vs + CK * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Kt + DH * LDT);
+    uint8_t* Mt = Ms + Sp;
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    for (int i = tid; i < Sp; i += 256) Ms[i] = (i >= S) ? 1 : (mask ? mask[(long)(n % mask_B) * S + i] : 0);
+    __syncthreads();
+    for (int t = tid; t < nkt; t += 256) {
+        uint8_t any = 0;
+        for (int j = 0; j < 32; ++j) any |= Ms[t * 32 + j];
+        Mt[t] = any;
+    }
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int it0 = 4 * DQ_SLOTS * (int)blockIdx.y;           // first query tile of this workgroup (grid.y splits the query tiles)
+
+    f32x16 dQ[DQ_SLOTS][DT];
+    float L2s[DQ_SLOTS], dls[DQ_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+        L2s[sl] = 0.f; dls[sl] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[sl][dt][i] = 0.f;
+    }
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const int kbase = ch * CK;                               // first key of the chunk
+        const int krows = min(CK, Sp - kbase);                  // staged rows of the chunk (multiple of 32)
+        __syncthreads();                                         // the previous chunk's readers are done (and Mt is written)
+        // rows beyond S are zero-filled by the staging helpers (their S / Sp arguments are chunk-relative)
+        stage_rows<DH, IOB>(Ks, qkv, base + E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), krows, tid, 256);
+        stage_rows<DH, IOB>(Vs, qkv, base + 2 * E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), krows, tid, 256);
+        stage_transposed<DH, IOB>(Kt, qkv, base + E + (long)kbase * ld, ld, max(0, min(S - kbase, krows)), CK, tid, 256);
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+            const int qt = it0 + wave + 4 * sl;
+            if (qt >= nqt) continue;
+            const int q = qt * 32 + c;
+            const int qc = min(q, S - 1);
+            bf16x8 qf[KS], df[KS];
+            float dl = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+                qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+                df[s] = load_frag8<IOB>(dctx, off);
+                if (ch == 0) {
+                    float dv[8], ov[8];
+                    load_f32x8<IOB>(dctx, off, dv);
+                    load_f32x8<IOB>(ctx, off, ov);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dl += dv[j] * ov[j];
+                }
+            }
+            if (ch == 0) {
+                dl += __shfl_xor(dl, 32, 64);
+                dls[sl] = dl;
+                L2s[sl] = q < S ? lse2[(long)blockIdx.x * S + q] : 0.f;
+                if (q < S && h == 0) delta[(long)blockIdx.x * S + q] = dl;
+            }
+            dl = dls[sl];
+            const float L2 = L2s[sl];
+            const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+            const int kt_lo = ch * ckt, kt_hi = min(nkt, kt_lo + ckt);      // key tiles of this chunk
+            for (int kt = kt_lo; kt < kt_hi; ++kt) {
+                const int lr = (kt - kt_lo) * 32;                 // first LDS row of the tile
+                f32x16 s16, dp16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (lr + c) * LDK + 16 * s + 8 * h);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (lr + c) * LDK + 16 * s + 8 * h);
+                    s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+                    dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
+                }
+                if (drop.p > 0.f) {
+                    const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                        dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                        dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                        dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                        dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt * 32 + acc_row(i, h);
+                        const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
+                        s16[i] = p * (dp16[i] - dl) * scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(s16[i] * sc - L2) * (dp16[i] - dl) * scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8 kf = frag_transposed(Kt, LDT, min(dt * 32 + c, DH - 1), lr, s2, h);
+                        dQ[sl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[sl][dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- outputs -------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int sl = 0; sl < DQ_SLOTS; ++sl) {
+        const int qt = it0 + wave + 4 * sl;
+        const bool live = qt < nqt;
+        const int q = qt * 32 + c;
+        if (live && q < S) {
+            const long out = ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {dQ[sl][dt][4 * g], dQ[sl][dt][4 * g + 1], dQ[sl][dt][4 * g + 2], dQ[sl][dt][4 * g + 3]};
+                        store4<IOB>(dqkv, out + d, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, dK / dV: keys on the lanes.  One WAVE per (sample, head, 32-key tile) - no workgroup barriers.
 // The wave keeps K, V fragments of its key tile and the dK^T, dV^T [dh x 32 keys] accumulators in
 // registers and walks all query tiles.  Per query tile it loads its 32 rows of Q and dO once: the packed
@@ -907,6 +1220,23 @@ size_t dq2_smem(int S, int DH) {
     const int CK = ((Sp / 32 + 1) / 2) * 32;
     return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
+// long-sequence kernels: keys stream through LDS in chunks of CK (a multiple of 32) chosen so that two workgroups share a CU
+constexpr int LONG_MAX_S = 2048;                 // 64 key-tile flags
+size_t fwd_long_smem(int S, int DH, int CK) {
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16;
+}
+size_t dq_long_smem(int S, int DH, int CK) {
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16;
+}
+template <typename F>
+int long_chunk(int S, int DH, F smem) {         // largest chunk with 2 * smem <= 160 KB (at least one key tile)
+    int ck = 32;
+    while (ck + 32 <= 512 && 2 * smem(S, DH, ck + 32) <= 160 * 1024) ck += 32;
+    return ck;
+}
+bool short_ok(int S, int dh) { return dq_smem(S, dh) <= 160 * 1024 && fwd_smem(S, dh) <= 160 * 1024; }
 template <typename K>
 int set_smem(K kernel, size_t bytes) {
     GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -919,7 +1249,7 @@ bool flash_attn_supported(int S, int E, int nh) {
     const int dh = E / nh;
     if (!(dh == 16 || dh == 32 || dh == 64)) return false;
     if (E % 4) return false;
-    return dq_smem(S, dh) <= 160 * 1024 && fwd_smem(S, dh) <= 160 * 1024;
+    return short_ok(S, dh) || S <= LONG_MAX_S;      // beyond the LDS-resident range: the key-streaming kernels
 }
 
 int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
@@ -927,12 +1257,20 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
     const int qB = (int)(qkv_B > 0 ? qkv_B : N);
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
-    const size_t sm = fwd_smem(S, dh);
-    const dim3 grid((unsigned)(N * nh));
+    static const bool force_long = getenv("GG_ATTN_LONG") != nullptr;      // A/B and tests: the key-streaming kernels at any S
+    const bool lng = force_long || !short_ok(S, dh);
+    const int ck = lng ? long_chunk(S, dh, fwd_long_smem) : 0;
+    const size_t sm = lng ? fwd_long_smem(S, dh, ck) : fwd_smem(S, dh);
+    const dim3 grid((unsigned)(N * nh), lng ? (unsigned)(((S + 31) / 32 + 3) / 4) : 1u);
 #define GG_FWD(D, B)                                                                                          \
     do {                                                                                                      \
-        GG_TRY(set_smem(&attn_fwd_kernel<D, B>, sm));                                                         \
-        hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
+        if (lng) {                                                                                            \
+            GG_TRY(set_smem(&attn_fwd_long_kernel<D, B>, sm));                                                \
+            hipLaunchKernelGGL((attn_fwd_long_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, ck); \
+        } else {                                                                                              \
+            GG_TRY(set_smem(&attn_fwd_kernel<D, B>, sm));                                                     \
+            hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
+        }                                                                                                     \
     } while (0)
     if (io_bf16) {
         if (dh == 64) GG_FWD(64, true);
@@ -963,9 +1301,17 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     const size_t sm2 = dq2_smem(S, dh);
     static const bool dq2_off = getenv("GG_ATTN_DQ1") != nullptr;
     const bool use_dq2 = !dq2_off && nqt_ >= 2 && items_q <= 4 * DQ_SLOTS && 2 * sm2 <= 160 * 1024;
+    static const bool force_long = getenv("GG_ATTN_LONG") != nullptr;
+    const bool lng = force_long || !short_ok(S, dh);
+    const int ck = lng ? long_chunk(S, dh, dq_long_smem) : 0;
+    const size_t sml = lng ? dq_long_smem(S, dh, ck) : 0;
+    const dim3 gridl((unsigned)(N * nh), (unsigned)((nqt_ + 4 * DQ_SLOTS - 1) / (4 * DQ_SLOTS)));
 #define GG_BWD(D, B)                                                                                                        \
     do {                                                                                                                    \
-        if (use_dq2) {                                                                                                      \
+        if (lng) {                                                                                                          \
+            GG_TRY(set_smem(&attn_bwd_dq_long_kernel<D, B>, sml));                                                          \
+            hipLaunchKernelGGL((attn_bwd_dq_long_kernel<D, B>), gridl, dim3(256), sml, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, ck); \
+        } else if (use_dq2) {                                                                                                      \
             GG_TRY(set_smem(&attn_bwd_dq2_kernel<D, B>, sm2));                                                              \
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<D, B>), grid, dim3(256), sm2, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
         } else {                                                                                                            \

@@ -34,9 +34,13 @@ CASES = {
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
-    # S = 601 > the fused attention kernels' LDS-resident key range: the unfused (GEMM + softmax + GEMM) route
+    # S = 601 > the LDS-resident key range of the short attention kernels: in bf16 mode the key-streaming ("long") kernels,
+    # in f32 parity mode the unfused (GEMM + softmax + GEMM) route
     "long_S601": dict(cfg=PathConfig(n_genes=64, latent_dims=16, embedding_dims=64, hidden_dims=32, text_dims=24,
                                       patch_dims=40, dropout=0.0), B=2, P=600, T=2),
+    # the same at the production head width (dh = 64), several query groups of the long dQ kernel (18 query tiles > 12)
+    "long_S545_E256": dict(cfg=PathConfig(n_genes=48, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=24,
+                                           patch_dims=32, dropout=0.0), B=2, P=544, T=1),
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
@@ -241,7 +245,7 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257"])
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_flash_attention_matches_unfused_path(case, dropout):
     """Fused attention forward/backward (attention.hip) against the unfused bf16 path (GEMM + softmax +
@@ -492,7 +496,7 @@ def test_side_streams_do_not_change_results(case):
 
 
 @pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256", "film_P1",
-                                  "film_P33_E256", "img_P40_E256"])
+                                  "film_P33_E256", "img_P40_E256", "long_S545_E256"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""
