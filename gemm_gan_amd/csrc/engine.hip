@@ -126,6 +126,7 @@ struct gg_engine {
     int precision = GG_PREC_F32;
     bool xattn = true;         // text<->image cross attention (conditional_gan_cross_attention_with_film.py); false: CLS row (conditional_gan_film.py)
     bool enc_bias = true;      // encoder layers with biases (bias=False in conditional_gan_film.py:115)
+    bool no_cond = false;      // unconditional model (vanilla_gan_unconditional.py): the conditioning vector is identically zero
     bool film = true;          // FiLM modulation of the patches from the text vector; false: conditional_gan_img_transformer.py
     bool pe_ln = false;        // patch encoder = Linear -> ReLU -> LayerNorm (conditional_gan_img_transformer.py:106-110)
     uint64_t seed = 0;
@@ -199,6 +200,26 @@ void build_net(gg_engine* e, int role) {
     const std::string mlp = role == GG_ROLE_GENERATOR ? "generator" : "discriminator";
     // visible parameters first, ghosts (see Net::add_ghost) behind them
     const bool xa = e->xattn, eb = e->enc_bias;
+    if (e->no_cond) {
+        // vanilla_gan_unconditional.py:93-184: MLP heads only.  The first layer keeps its [H, V + E] storage with E zero
+        // columns (the conditioning vector is zero, so their gradient is exactly zero and they stay zero); hosts see [:, :V]
+        n.w1 = n.add(mlp + ".0.0.weight", H, n.V + E);
+        n.b1 = n.add(mlp + ".0.0.bias", H);
+        n.w2 = n.add(mlp + ".1.0.weight", H, H);
+        n.b2 = n.add(mlp + ".1.0.bias", H);
+        n.w3 = n.add("final_layer.weight", n.OUT, H);
+        n.b3 = n.add("final_layer.bias", n.OUT);
+        n.live = n.total;
+        const long gh = n.add_ghost(8);           // never read: cond_forward / cond_backward return before touching them
+        n.cls = n.film_w = n.film_b = n.te_w = n.te_b = n.pe_w = n.pe_b = gh;
+        for (int l = 0; l < e->nl; ++l) {
+            LayerP& L = n.layer[l];
+            L.sa.inw = L.sa.inb = L.sa.ow = L.sa.ob = L.l1w = L.l1b = L.l2w = L.l2b = L.n1w = L.n1b = L.n2w = L.n2b = gh;
+        }
+        n.t2i.inw = n.t2i.inb = n.t2i.ow = n.t2i.ob = gh;
+        n.i2t = n.t2i;
+        return;
+    }
     n.cls = n.add("patches_cls_token", 1, 1, E);
     if (e->film) {
         n.film_w = n.add("film_generator.weight", 2 * Dp, Dt);
@@ -592,6 +613,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     const long RB = (long)R * B;
     const long keep_rows = keep < 0 ? -1 : (long)keep * B * S;
     a.B = B; a.R = R; a.P = P; a.T = T; a.drop = drop; a.call = ++e->call_counter;
+    if (e->no_cond) {        // unconditional model: c == 0
+        KL(k_fill(a.c, RB * E, 0.f, c.st));
+        return 0;
+    }
     const float* w = n.w;
     // FiLM parameters from the text CLS token (row b of `text` viewed with ld = T*Dt)
     if (e->film) {
@@ -843,6 +868,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const float ks = drop > 0.f ? 1.f / (1.f - drop) : 1.f;
     const int bst = a.bst ? 1 : 0;
 
+    if (e->no_cond) {        // nothing upstream of the (zero) conditioning vector; join the head's side-stream leaves
+        for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));
+        return 0;
+    }
     bool i2t_sh = false;
     if (!e->xattn) {    // the conditioning vector was the encoder's CLS row: its gradient is the only non-zero row per sample
         KL(k_fill(e->sdx, RB * S * E, 0.f, c.st));
@@ -1448,7 +1477,9 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->cfg = *cfg;
     e->E = cfg->embedding_dims; e->F = 2 * e->E; e->H = cfg->hidden_dims; e->G = cfg->n_genes; e->L = cfg->latent_dims;
     e->Dt = cfg->text_dims; e->Dp = cfg->patch_dims; e->nh = cfg->n_heads; e->nl = cfg->n_layers; e->dh = e->E / e->nh;
-    GG_REQUIRE(cfg->variant >= GG_VARIANT_XATTN_FILM && cfg->variant <= GG_VARIANT_IMG, "unknown variant");
+    GG_REQUIRE(cfg->variant >= GG_VARIANT_XATTN_FILM && cfg->variant <= GG_VARIANT_VANILLA, "unknown variant");
+    e->no_cond = cfg->variant == GG_VARIANT_VANILLA;
+    GG_REQUIRE(!e->no_cond || cfg->dropout == 0.f, "the unconditional variant has no dropout site");
     e->xattn = cfg->variant == GG_VARIANT_XATTN_FILM;
     e->enc_bias = cfg->variant == GG_VARIANT_XATTN_FILM;
     e->film = cfg->variant != GG_VARIANT_IMG;

@@ -85,7 +85,11 @@ class Engine:
     # -- parameter access ------------------------------------------------------------------------
     def view(self, role, name, which="w") -> torch.Tensor:
         off, numel, shape = self.layout[role][name]
-        return self.flat[role][which][off:off + numel].view(shape)
+        t = self.flat[role][which][off:off + numel].view(shape)
+        if self.variant == "vanilla" and name.endswith(".0.0.weight"):
+            # GG_VARIANT_VANILLA keeps embedding_dims zero columns behind the reference's [H, V] first-layer weight
+            t = t[:, : shape[1] - self.cfg.embedding_dims]
+        return t
 
     def load_state(self, role, state: Dict[str, torch.Tensor]):
         for name in self.layout[role]:

@@ -53,6 +53,9 @@ extern "C" {
 
 #define GG_VARIANT_IMG 2        /* src/conditional_gan_img_transformer.py:95-190: no FiLM, patch encoder Linear -> ReLU ->  */
                                 /* LayerNorm (R'':106-110), bias-free encoder, CLS-row conditioning; text is unused         */
+#define GG_VARIANT_VANILLA 3    /* src/vanilla_gan_unconditional.py:93-184: MLP generator / critic without conditioning.    */
+                                /* The first-layer weights keep embedding_dims zero columns: gg_param_info reports            */
+                                /* [H, V + embedding_dims], the reference's tensor is the [:, :V] block; cond inputs ignored  */
 
 typedef struct gg_config {
     /* model shape: WGAN_GP.__init__ kwargs R:258-271, generator/discriminator ctors R:99, R:169 */

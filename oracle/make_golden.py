@@ -134,30 +134,41 @@ def sd_to_np(prefix, sd, out, stride=1):
 class Calls:
     """The two reference files differ in argument order / text rank; fixtures store text as [B,T,Dt] for both."""
 
-    def __init__(self, film):
+    def __init__(self, film, vanilla=False):
         self.film = film
+        self.vanilla = vanilla
 
     def net(self, net, v, inp):
+        if self.vanilla:    # vanilla_gan_unconditional.py:122 / :169: forward(x)
+            return net(v)
         if self.film:       # conditional_gan_film.py:130 / :183: (x, text_embedding [B,Dt], patches, padding_mask)
             return net(v, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
         return net(v, inp["patches"], inp["patch_pad"], inp["text"], inp["text_pad"])
 
     def train_disc(self, w, x, z, inp):
+        if self.vanilla:
+            return w.train_disc(x, z)
         if self.film:
             return w.train_disc(x, z, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
         return w.train_disc(x, z, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
 
     def train_gen(self, w, z, inp):
+        if self.vanilla:
+            return w.train_gen(z)
         if self.film:
             return w.train_gen(z, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
         return w.train_gen(z, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
 
     def train(self, w, x, inp):
+        if self.vanilla:
+            return w.train(x)
         if self.film:
             return w.train(x, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
         return w.train(x, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
 
     def generate(self, w, x, inp):
+        if self.vanilla:
+            return w.generate_samples(x)
         if self.film:
             return w.generate_samples(x, inp["text"][:, 0, :], inp["patches"], inp["patch_pad"])
         return w.generate_samples(x, inp["text"], inp["text_pad"], inp["patches"], inp["patch_pad"])
@@ -168,6 +179,17 @@ def grads_of(net):
 
 
 def build(ref, dims, optimizer, init=None):
+    if dims.get("variant") == "vanilla":
+        # WGAN_GP_nocond(input_dims, latent_dims, vocab_sizes, generator_dims, discriminator_dims, ...) (V:214)
+        w = ref.WGAN_GP_nocond(dims["G"], dims["L"], [], [dims["H"], dims["H"], dims["G"]], [dims["H"], dims["H"], 1],
+                               negative_slope=dims.get("slope", 0.0), optimizer=optimizer, n_critic=dims["n_critic"],
+                               results_dire="/tmp/_gemmgan_golden")
+        w.build_WGAN_GP_nocond()
+        if init is not None:
+            w.gen.load_state_dict(init[0])
+            w.disc.load_state_dict(init[1])
+        w.init_train()
+        return w
     w = ref.WGAN_GP(dims["G"], dims["L"], dims["E"], [dims["H"], dims["H"], dims["G"]],
                     [dims["H"], dims["H"], 1], text_embedding_dims=dims["Dt"],
                     patches_embedding_dims=dims["Dp"], negative_slope=dims.get("slope", 0.0),
@@ -191,6 +213,12 @@ def stage_hooks(net, role, taps):
         return fn
     if hasattr(net, "film_generator"):
         hs.append(net.film_generator.register_forward_hook(tap("film_pre")))
+    if not hasattr(net, "patches_encoder"):          # unconditional nets: the MLP only
+        blocks = getattr(net, role)
+        for i, blk in enumerate(blocks):
+            hs.append(blk[0].register_forward_hook(tap(f"mlp_pre{i}")))
+        hs.append(net.final_layer.register_forward_hook(tap("out")))
+        return hs
     if hasattr(net, "text_encoder"):
         hs.append(net.text_encoder.register_forward_hook(tap("text_enc")))
     hs.append(net.patches_encoder.register_forward_hook(tap("patch_emb")))
@@ -213,7 +241,7 @@ def make_fixture(ref, name, dims, seed):
     out["slope"] = np.float32(dims.get("slope", 0.0))
     film = dims.get("variant", "xattn_film") in ("film", "img")      # the 4-argument files
     out["variant"] = np.array(dims.get("variant", "xattn_film"))
-    call = Calls(film)
+    call = Calls(film, dims.get("variant") == "vanilla")
     torch.manual_seed(seed)
     w0 = build(ref, dims, "rms_prop")
     init = (copy.deepcopy(w0.gen.state_dict()), copy.deepcopy(w0.disc.state_dict()))
@@ -263,7 +291,7 @@ def make_fixture(ref, name, dims, seed):
     out["critic1/alpha"] = rec.alpha[0].numpy()
     out["critic1/grad_x_hat"] = rec.gp_grads[0].numpy()
     out["critic1/losses"] = np.array([float(w1.disc_loss), *w1.d_batch_loss], dtype=np.float64)
-    if film:        # no clipping in this file (conditional_gan_film.py:383-385): the gradients are still on the parameters
+    if film or call.vanilla:        # no clipping in these files: the gradients are still on the parameters
         pre = grads_of(w1.disc)
     else:
         pre, tot, mx = rec.clips[0]
@@ -282,7 +310,7 @@ def make_fixture(ref, name, dims, seed):
         call.train_gen(w2, z2, inp)
     out["gen1/z"] = z2.numpy()
     out["gen1/loss"] = np.float64(float(w2.gen_loss))
-    if film:
+    if film or call.vanilla:
         pre = grads_of(w2.gen)
     else:
         pre, tot, mx = rec.clips[0]
@@ -294,7 +322,7 @@ def make_fixture(ref, name, dims, seed):
 
     # ---- full train() (:463-477) for the three optimisers
     # conditional_gan_img_transformer.py:277-286 knows rms_prop and adam only
-    for opt in (("rms_prop", "adam") if dims.get("variant") == "img" else ("rms_prop", "adam", "adamw")):
+    for opt in (("rms_prop", "adam") if dims.get("variant") in ("img", "vanilla") else ("rms_prop", "adam", "adamw")):
         w = build(ref, dims, opt, init)
         torch.manual_seed(seed + 5)
         with Recorder() as rec:
@@ -327,9 +355,12 @@ FIXTURES = {
     "film_P7": dict(B=4, G=33, P=7, T=1, Dt=16, Dp=24, E=32, H=16, L=8, n_critic=2, variant="film", slope=0.1),
     # image-transformer sibling (src/conditional_gan_img_transformer.py; BASELINE configs[4] family)
     "img_P9": dict(B=5, G=45, P=9, T=1, Dt=12, Dp=28, E=32, H=24, L=10, n_critic=3, variant="img"),
+    # unconditional model (src/vanilla_gan_unconditional.py; BASELINE configs[0] family).  P, T, Dt, Dp, E only size the
+    # dummy conditioning inputs the engine's entry points still take
+    "vanilla_G60": dict(B=7, G=60, P=1, T=1, Dt=8, Dp=8, E=8, H=20, L=12, n_critic=5, variant="vanilla", slope=0.2),
 }
 REF_MODULE = {"xattn_film": "conditional_gan_cross_attention_with_film", "film": "conditional_gan_film",
-              "img": "conditional_gan_img_transformer"}
+              "img": "conditional_gan_img_transformer", "vanilla": "vanilla_gan_unconditional"}
 
 
 def main():

@@ -59,6 +59,7 @@ class PathConfig:
     # film_config() so the clip fields follow
     # "img": src/conditional_gan_img_transformer.py (I:95-190) - like "film" but without FiLM: the patch encoder is
     # Linear -> ReLU -> LayerNorm on the raw patches (I:106-110), the text input is unused
+    # "vanilla": src/vanilla_gan_unconditional.py (V:93-184) - MLP generator / critic, no conditioning inputs at all
     variant: str = "xattn_film"
 
     @property
@@ -80,6 +81,14 @@ def img_config(**kw) -> PathConfig:
     return PathConfig(variant="img", **kw)
 
 
+def vanilla_config(**kw) -> PathConfig:
+    """PathConfig of the unconditional model (src/vanilla_gan_unconditional.py): no conditioning, no dropout, no clipping."""
+    kw.setdefault("clip_d", None)
+    kw.setdefault("clip_g", None)
+    kw.setdefault("dropout", 0.0)
+    return PathConfig(variant="vanilla", **kw)
+
+
 def _mlp_block(n_in: int, n_out: int, slope: float) -> nn.Sequential:
     # build_linear_block (:56-74) with is_bn=False: Linear followed by LeakyReLU(slope)
     return nn.Sequential(nn.Linear(n_in, n_out), nn.LeakyReLU(negative_slope=slope))
@@ -97,8 +106,14 @@ class CondNet(nn.Module):
         assert role in ("generator", "discriminator")
         self.role, self.cfg = role, cfg
         E, Dt, Dp = cfg.embedding_dims, cfg.text_dims, cfg.patch_dims
+        assert cfg.variant in ("xattn_film", "film", "img", "vanilla")
+        if cfg.variant == "vanilla":                      # V:110-113 / V:158-161: the MLP on the raw vector
+            first = cfg.latent_dims if role == "generator" else cfg.n_genes
+            H = cfg.hidden_dims
+            setattr(self, role, nn.ModuleList([_mlp_block(first, H, cfg.negative_slope), _mlp_block(H, H, cfg.negative_slope)]))
+            self.final_layer = nn.Linear(H, cfg.n_genes if role == "generator" else 1)
+            return
         film_only = cfg.variant in ("film", "img")       # no token encoder / cross attention, bias-free encoder
-        assert cfg.variant in ("xattn_film", "film", "img")
         if cfg.variant != "img":
             self.film_generator = nn.Linear(Dt, 2 * Dp)
         if not film_only:
@@ -126,6 +141,8 @@ class CondNet(nn.Module):
 
     # -- conditioning stack shared by both roles (:129-155 == :198-224) ------------------------
     def conditioning(self, patches, patch_pad, text, text_pad, taps: Optional[dict] = None):
+        if self.cfg.variant == "vanilla":
+            return None
         Dp = self.cfg.patch_dims
         if self.cfg.variant == "img":                     # I:126: the encoder sees the raw patches; text is unused
             gamma = beta = None
@@ -155,7 +172,7 @@ class CondNet(nn.Module):
         return c
 
     def head(self, v, c, taps: Optional[dict] = None):
-        h = torch.cat((v, c), dim=1)
+        h = v if c is None else torch.cat((v, c), dim=1)
         for i, blk in enumerate(getattr(self, self.role)):
             pre = blk[0](h)
             h = blk[1](pre)

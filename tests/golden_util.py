@@ -4,11 +4,11 @@ import os
 import numpy as np
 import torch
 
-from oracle.torch_oracle import CondNet, PathConfig, Trainer, film_config, img_config, set_dropout
+from oracle.torch_oracle import CondNet, PathConfig, Trainer, film_config, img_config, set_dropout, vanilla_config
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # xattn_film_*: from src/conditional_gan_cross_attention_with_film.py; film_*: from src/conditional_gan_film.py
-FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky", "film_P1", "film_P7", "img_P9"]
+FIXTURES = ["xattn_film_T3", "xattn_film_T1_leaky", "film_P1", "film_P7", "img_P9", "vanilla_G60"]
 XATTN_FIXTURES = [f for f in FIXTURES if f.startswith("xattn_")]
 
 
@@ -24,10 +24,10 @@ class Golden:
 
     def cfg(self, optimizer="rms_prop") -> PathConfig:
         d = self.dims
-        make = {"film": film_config, "img": img_config}.get(self.variant, PathConfig)
+        make = {"film": film_config, "img": img_config, "vanilla": vanilla_config}.get(self.variant, PathConfig)
         return make(n_genes=d["G"], latent_dims=d["L"], embedding_dims=d["E"], hidden_dims=d["H"],
-                          text_dims=d["Dt"], patch_dims=d["Dp"], negative_slope=self.slope, dropout=0.0,
-                          optimizer=optimizer, n_critic=d["n_critic"])
+                    text_dims=d["Dt"], patch_dims=d["Dp"], negative_slope=self.slope, dropout=0.0,
+                    optimizer=optimizer, n_critic=d["n_critic"])
 
     def t(self, key):
         return torch.from_numpy(np.asarray(self.z[key]))

@@ -46,6 +46,7 @@ def _create(g: Golden, **over):
 @pytest.mark.parametrize("name", FIXTURES)
 def test_layout_is_the_live_state_dict(name):
     g = Golden(name)
+    d = g.dims
     lib = L.load()
     rc, h = _create(g)
     assert rc == 0, lib.gg_last_error()
@@ -63,7 +64,10 @@ def test_layout_is_the_live_state_dict(name):
         assert end <= lib.gg_flat_numel(h, role)
         assert set(seen) == set(ref)
         for k, shp in seen.items():
-            assert shp == tuple(ref[k].shape), k
+            if g.variant == "vanilla" and k.endswith(".0.0.weight"):       # GG_VARIANT_VANILLA: embedding_dims zero columns appended
+                assert shp == (ref[k].shape[0], ref[k].shape[1] + d["E"]), k
+            else:
+                assert shp == tuple(ref[k].shape), k
     assert lib.gg_workspace_bytes(h) > 0
     lib.gg_destroy(h)
 
@@ -91,8 +95,11 @@ def test_facade_state_dict_matches_reference_keys(name):
     g = Golden(name)
     d = g.dims
     mod = {"film": gga.film, "img": gga.img_transformer}.get(g.variant, gga)   # the mirror module of the fixture's reference file
-    gen, disc = mod.WGAN_GP_model(d["L"], d["G"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1],
-                                  d["Dt"], d["Dp"], g.slope, False)
+    if g.variant == "vanilla":
+        gen, disc = gga.vanilla.WGAN_GP_model_nocond(d["L"], d["G"], [], [], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], g.slope, False)
+    else:
+        gen, disc = mod.WGAN_GP_model(d["L"], d["G"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1],
+                                      d["Dt"], d["Dp"], g.slope, False)
     for net, prefix in ((gen, "init_gen"), (disc, "init_disc")):
         ref = g.group(prefix)
         sd = net.state_dict()
@@ -101,7 +108,7 @@ def test_facade_state_dict_matches_reference_keys(name):
             assert tuple(sd[k].shape) == tuple(ref[k].shape), k
         net.load_state_dict(g.state(prefix), strict=True)
     with pytest.raises(RuntimeError, match="not bound"):
-        disc(*[torch.zeros(1)] * (5 if g.variant == "xattn_film" else 4))
+        disc(*[torch.zeros(1)] * {"xattn_film": 5, "vanilla": 1}.get(g.variant, 4))
 
 
 @pytest.mark.parametrize("idx", [0, 2, 4])

@@ -40,6 +40,14 @@ def test_forward_stages(name):
     out = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=True)
     ref = g.group("disc_fwd")
     B, P, S, E, Dp = d["B"], d["P"], d["P"] + 1, d["E"], d["Dp"]
+    if g.variant == "vanilla":       # no conditioning stack: outputs only
+        ck.check("critic score", out, ref["out"])
+        xg = eng.forward(L.ROLE_GENERATOR, g.t("gen_fwd/z").cuda(), patches, patch_pad, text, text_pad, train=True)
+        ck.check("generated genes", xg, g.z["gen_fwd/out"])
+        xe = eng.forward(L.ROLE_GENERATOR, g.t("infer/z").cuda(), patches, patch_pad, text, text_pad, train=False)
+        ck.check("generate_samples (eval)", xe, g.z["infer/x_gen"])
+        ck.done()
+        return
     if g.variant != "img":
         gb = eng.debug_buffer("D.gb").view(B, 2 * Dp)
         ck.check("film gamma", gb[:, :Dp], np.tanh(ref["film_pre"][:, :Dp]))

@@ -83,3 +83,55 @@ def test_reference_call_signatures_and_fit(tmp_path):
     assert set(sd) == set(g.group("init_gen"))                  # a checkpoint the reference's load_state_dict accepts
     with pytest.raises(NotImplementedError):
         w.gradient_penalty(x, x, emb, patches, patch_pad)
+
+
+def test_vanilla_mirror_golden_train_step(tmp_path):
+    """gemm_gan_amd.vanilla <-> src/vanilla_gan_unconditional.py (BASELINE configs[0]): names, shapes (the engine's padded
+    first-layer weight shows up as the reference's [H, V] block), a full train() with the recorded noise, inference, fit()."""
+    from gemm_gan_amd import vanilla
+    g = Golden("vanilla_G60")
+    d = g.dims
+    w = vanilla.WGAN_GP_nocond(d["G"], d["L"], [], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], negative_slope=g.slope,
+                               n_critic=d["n_critic"], device="cuda:0", results_dire=str(tmp_path))
+    w.build_WGAN_GP_nocond()
+    w.init_train()
+    for net, prefix in ((w.gen, "init_gen"), (w.disc, "init_disc")):
+        ref = g.group(prefix)
+        sd = net.state_dict()
+        assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+        net.load_state_dict(g.state(prefix))
+    x = g.inputs()[0].cuda()
+    ck = Checker("vanilla mirror", 1e-3)
+    w.gen.eval()
+    ck.check("generator forward (eval)", w.gen(g.t("infer/z").cuda()), g.z["infer/x_gen"])
+    w.disc.train()
+    ck.check("critic forward", w.disc(x), g.group("disc_fwd")["out"])
+    z_all = g.t("step_rms_prop/z").cuda().contiguous()
+    alpha_all = g.t("step_rms_prop/alpha").cuda().reshape(z_all.shape[0] - 1, -1).contiguous()
+    w.train_with_explicit_noise(x, z_all, alpha_all)
+    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"], tol=5e-3)
+    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]), tol=5e-3)
+    for role, net in (("gen", w.gen), ("disc", w.disc)):
+        sd = net.state_dict()
+        steps = 1 if role == "gen" else d["n_critic"]
+        for n, ref in g.group(f"step_rms_prop/post_{role}").items():
+            err = np.abs(sd[n].detach().cpu().numpy().reshape(-1) - ref.reshape(-1)).max()
+            move = np.abs(ref.reshape(-1) - g.z[f"init_{role}/{n}"].reshape(-1)).max()
+            assert err <= 0.25 * steps * 5e-3 + 1e-3 * move + 1e-6, (role, n, err)
+    # the padded columns of the engine's first-layer weights are still exactly zero after six optimiser steps
+    for role in (0, 1):
+        name = [k for k in w.engine.layout[role] if k.endswith(".0.0.weight")][0]
+        off, numel, shape = w.engine.layout[role][name]
+        full = w.engine.flat[role]["w"][off:off + numel].view(shape)
+        assert float(full[:, shape[1] - w.engine.cfg.embedding_dims:].abs().max()) == 0.0
+    ck.done()
+    w.train(x)
+    w.train_disc(x, torch.randn(d["B"], d["L"]))
+    w.train_gen(torch.randn(d["B"], d["L"]))
+    x_real, x_gen = w.generate_samples(x)
+    assert tuple(x_gen.shape) == (d["B"], d["G"]) and torch.isfinite(x_gen).all()
+    w2 = vanilla.WGAN_GP_nocond(d["G"], d["L"], [], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], n_critic=2, device="cuda:0",
+                                results_dire=str(tmp_path), freq_compute_test=1)
+    hist = w2.fit([(x.cpu(),)] * 2, epochs=2)
+    assert len(hist["d loss"]) == 2 and all(np.isfinite(v) for v in hist["d loss"] + hist["g loss"])
+    assert set(torch.load(tmp_path / "generator_last_epoch.pt")) == set(g.group("init_gen"))
