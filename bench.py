@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--tokens", type=int, default=1)
     ap.add_argument("--text-dims", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--variant", choices=["xattn_film", "film", "img"], default="xattn_film",
+    ap.add_argument("--variant", choices=["xattn_film", "film", "img", "vanilla"], default="xattn_film",
                     help="xattn_film: the headline path (conditional_gan_cross_attention_with_film.py); film: the FiLM-only "
                          "sibling (conditional_gan_film.py; BASELINE configs[1] is --variant film --patches 1); img: "
-                         "conditional_gan_img_transformer.py (configs[4] per rank: --variant img --batch 128 --genes 18000 --patches 1024)")
+                         "conditional_gan_img_transformer.py (configs[4] per rank: --variant img --batch 128 --genes 18000 --patches 1024); "
+                         "vanilla: vanilla_gan_unconditional.py (configs[0]: --variant vanilla --batch 64 --genes 1000 --dropout 0)")
     ap.add_argument("--pad-frac", type=float, default=0.0,
                     help="fraction of samples whose last P/4 patch tokens are padded (SURVEY 8d masking run: 0.25)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="bf16",
@@ -98,11 +99,11 @@ def log(msg):
 def cpu_baseline(args):
     """Oracle #1 (stock torch modules on the host CPU, the reference's own arithmetic) timed on a
     bounded sample: the same workload at a smaller minibatch, 1 warm-up + up to 12 timed train() steps (about 20 s)."""
-    from oracle.torch_oracle import PathConfig, Trainer, film_config, img_config, synthetic_batch
+    from oracle.torch_oracle import PathConfig, Trainer, film_config, img_config, synthetic_batch, vanilla_config
     cores = host_cores()
     torch.set_num_threads(cores)
-    make = {"film": film_config, "img": img_config}.get(args.variant, PathConfig)
-    cfg = make(n_genes=args.genes, text_dims=args.text_dims, dropout=args.dropout)
+    make = {"film": film_config, "img": img_config, "vanilla": vanilla_config}.get(args.variant, PathConfig)
+    cfg = make(n_genes=args.genes, text_dims=args.text_dims, dropout=0.0 if args.variant == "vanilla" else args.dropout)
     Bc = args.cpu_batch
     torch.manual_seed(42)
     tr = Trainer(cfg)
@@ -163,9 +164,14 @@ def main():
     if film and T != 1:
         raise SystemExit("--variant film / img take one text vector per sample (--tokens 1)")
     cls = {"film": gga.film.WGAN_GP, "img": gga.img_transformer.WGAN_GP}.get(args.variant, gga.WGAN_GP)
-    w = cls(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
-                    optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="",
-                    precision=args.precision)
+    vanilla = args.variant == "vanilla"
+    if vanilla:
+        w = gga.vanilla.WGAN_GP_nocond(G, Lz, [], [H, H, G], [H, H, 1], optimizer="rms_prop", n_critic=5, seed=1234 + rank,
+                                       device=dev, results_dire="", precision=args.precision)
+    else:
+        w = cls(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=args.text_dims, patches_embedding_dims=1024,
+                optimizer="rms_prop", n_critic=5, dropout=args.dropout, seed=1234 + rank, device=dev, results_dire="",
+                precision=args.precision)
     w.build_WGAN_GP()
     w.init_train()
     w.reserve(B, P, T)
@@ -179,7 +185,9 @@ def main():
     text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
 
     def train_once():
-        if film:
+        if vanilla:
+            w.train(x)
+        elif film:
             w.train(x, text[:, 0, :], patches, patch_pad)
         else:
             w.train(x, text, text_pad, patches, patch_pad)
@@ -252,7 +260,8 @@ def main():
         out = {"metric": "WGAN-GP samples/sec (n_critic=5, 5k-gene)", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": ("configs[4] family: conditional_gan_img_transformer.py train(), " if args.variant == "img" else
+               "config": {"workload": ("configs[0] family: vanilla_gan_unconditional.py train() (no conditioning inputs), " if vanilla else
+                                       "configs[4] family: conditional_gan_img_transformer.py train(), " if args.variant == "img" else
                                        "configs[1] family: conditional_gan_film.py train(), " if film else
                                        "configs[2]/[3]: conditional_gan_cross_attention_with_film.py train(), ")
                                       + f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
