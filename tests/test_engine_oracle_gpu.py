@@ -525,3 +525,36 @@ def test_bf16_mode_on_generic_shapes(case):
     diag(f"   flat critic gradient cosine: {total:.5f}")
     assert total >= 0.95, total
     ck.done()
+
+
+def test_call_time_errors_and_nan_semantics():
+    """Boundary behaviour (SURVEY 8b 'Errors' / 'Tensor conventions'): shape mistakes raise Python exceptions, exceeding the
+    reserved capacity is an error code (never an abort), and a fully padded text row yields NaN exactly as torch does."""
+    c = CASES["mid_T5_ragged"]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    set_dropout(tr.gen, 0.0)
+    set_dropout(tr.disc, 0.0)
+    x, text, text_pad, patches, patch_pad = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+    load_oracle_state(eng, tr)
+    xg, tg, tpg, pg, ppg = dev(x, text, text_pad, patches, patch_pad)
+    with pytest.raises(ValueError):
+        eng.forward(L.ROLE_CRITIC, xg, pg[:, :, :-1].contiguous(), ppg, tg, tpg)                  # wrong patch width
+    with pytest.raises(ValueError):
+        eng.forward(L.ROLE_CRITIC, xg, pg, ppg[:, :-1].contiguous(), tg, tpg)                     # mask / patches disagree
+    big = torch.cat([pg, pg], dim=0)
+    with pytest.raises(RuntimeError):
+        eng.forward(L.ROLE_CRITIC, torch.cat([xg, xg]), big, torch.cat([ppg, ppg]), torch.cat([tg, tg]), torch.cat([tpg, tpg]))
+    ok = eng.forward(L.ROLE_CRITIC, xg, pg, ppg, tg, tpg)                                          # the engine is still usable
+    assert torch.isfinite(ok).all()
+    tp2 = text_pad.clone()
+    tp2[2, :] = True                                                                                # every text key of sample 2 padded
+    tr.disc.eval()
+    with torch.no_grad():
+        ref = tr.disc(x, patches, patch_pad, text, tp2)
+    got = eng.forward(L.ROLE_CRITIC, xg, pg, ppg, tg, tp2.cuda())
+    assert torch.isnan(ref[2]).all() and torch.isnan(got[2]).all()
+    keep = [i for i in range(B) if i != 2]
+    assert torch.allclose(got[keep].cpu(), ref[keep], rtol=1e-3, atol=1e-5)
