@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
 template <int DH, bool IOB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                        int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
-                                                       int S, int E, int nh, DropKey drop, int qkv_B, int CK) {
+                                                       int S, int E, int nh, DropKey drop, int qkv_B, int CK, int npairs, int nqg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -361,7 +361,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
     constexpr int DT = (DH + 31) / 32;          // head-dim tiles of the O^T accumulator
     constexpr int KS = DH / 16;                 // k-steps of the score product
 
-    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    // XCD-aware order: workgroup b runs on XCD b % 8; the nqg query groups of one (sample, head) pair are consecutive
+    // slots of ONE XCD, so the pair's K / V chunks are re-read from that XCD's L2, not from HBM
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
@@ -379,8 +384,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
     const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     const int nqt = Sp / 32;
-    // one query tile per wave: tile 4 * blockIdx.y + wave; waves past the end still take part in the staging barriers
-    const int qt = 4 * (int)blockIdx.y + wave;
+    // one query tile per wave: tile 4 * (query group) + wave; waves past the end still take part in the staging barriers
+    const int qt = 4 * qg + wave;
     const bool active = qt < nqt;
     {
         const int q = qt * 32 + c;
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
         // dropout stream state of this lane's row at its first key pair (drop_rng.h: linear in the pair index)
-        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+        const uint32_t srow = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
         for (int kbase = 0; kbase < Sp; kbase += CK) {
         const int krows = min(CK, Sp - kbase);             // staged rows of this chunk (multiple of 32)
         __syncthreads();                                   // the previous chunk's readers are done (first pass: Mt is written)
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
                         store4<IOB>(ctx, out + d, v);
                     }
                 }
-            if (h == 0) lse2[(long)blockIdx.x * S + q] = m + log2f(l);
+            if (h == 0) lse2[(long)pair * S + q] = m + log2f(l);
         }
     }
 }
@@ -882,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
                                                               const void* __restrict__ dctx,
                                                               const float* __restrict__ lse2, float* __restrict__ delta,
                                                               const uint8_t* __restrict__ mask, int mask_B,
-                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B, int CK) {
+                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B, int CK, int npairs, int nqg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     const int nqt = Sp / 32, nkt = Sp / 32;
@@ -898,7 +903,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
     constexpr int DT = (DH + 31) / 32;
     constexpr int KS = DH / 16;
 
-    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    // XCD-aware order (see attn_fwd_long_kernel): the query groups of one (sample, head) pair share an XCD's L2
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
@@ -914,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-    const int it0 = 4 * DQ_SLOTS * (int)blockIdx.y;           // first query tile of this workgroup (grid.y splits the query tiles)
+    const int it0 = 4 * DQ_SLOTS * qg;           // first query tile of this workgroup (grid.y splits the query tiles)
 
     f32x16 dQ[DQ_SLOTS][DT];
     float L2s[DQ_SLOTS], dls[DQ_SLOTS];
@@ -960,12 +969,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
             if (ch == 0) {
                 dl += __shfl_xor(dl, 32, 64);
                 dls[sl] = dl;
-                L2s[sl] = q < S ? lse2[(long)blockIdx.x * S + q] : 0.f;
-                if (q < S && h == 0) delta[(long)blockIdx.x * S + q] = dl;
+                L2s[sl] = q < S ? lse2[(long)pair * S + q] : 0.f;
+                if (q < S && h == 0) delta[(long)pair * S + q] = dl;
             }
             dl = dls[sl];
             const float L2 = L2s[sl];
-            const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+            const uint32_t srow = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
             const int kt_lo = ch * ckt, kt_hi = min(nkt, kt_lo + ckt);      // key tiles of this chunk
             for (int kt = kt_lo; kt < kt_hi; ++kt) {
                 const int lr = (kt - kt_lo) * 32;                 // first LDS row of the tile
@@ -1261,12 +1270,13 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
     const bool lng = force_long || !short_ok(S, dh);
     const int ck = lng ? long_chunk(S, dh, fwd_long_smem) : 0;
     const size_t sm = lng ? fwd_long_smem(S, dh, ck) : fwd_smem(S, dh);
-    const dim3 grid((unsigned)(N * nh), lng ? (unsigned)(((S + 31) / 32 + 3) / 4) : 1u);
+    const int nqg = ((S + 31) / 32 + 3) / 4;                  // long kernels: query groups of four tiles
+    const dim3 grid(lng ? (unsigned)(((N * nh + 7) / 8) * 8 * nqg) : (unsigned)(N * nh));
 #define GG_FWD(D, B)                                                                                          \
     do {                                                                                                      \
         if (lng) {                                                                                            \
             GG_TRY(set_smem(&attn_fwd_long_kernel<D, B>, sm));                                                \
-            hipLaunchKernelGGL((attn_fwd_long_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, ck); \
+            hipLaunchKernelGGL((attn_fwd_long_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, ck, (int)(N * nh), nqg); \
         } else {                                                                                              \
             GG_TRY(set_smem(&attn_fwd_kernel<D, B>, sm));                                                     \
             hipLaunchKernelGGL((attn_fwd_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
@@ -1305,12 +1315,13 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     const bool lng = force_long || !short_ok(S, dh);
     const int ck = lng ? long_chunk(S, dh, dq_long_smem) : 0;
     const size_t sml = lng ? dq_long_smem(S, dh, ck) : 0;
-    const dim3 gridl((unsigned)(N * nh), (unsigned)((nqt_ + 4 * DQ_SLOTS - 1) / (4 * DQ_SLOTS)));
+    const int nqgl = (nqt_ + 4 * DQ_SLOTS - 1) / (4 * DQ_SLOTS);
+    const dim3 gridl((unsigned)(((N * nh + 7) / 8) * 8 * nqgl));
 #define GG_BWD(D, B)                                                                                                        \
     do {                                                                                                                    \
         if (lng) {                                                                                                          \
             GG_TRY(set_smem(&attn_bwd_dq_long_kernel<D, B>, sml));                                                          \
-            hipLaunchKernelGGL((attn_bwd_dq_long_kernel<D, B>), gridl, dim3(256), sml, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, ck); \
+            hipLaunchKernelGGL((attn_bwd_dq_long_kernel<D, B>), gridl, dim3(256), sml, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, ck, (int)(N * nh), nqgl); \
         } else if (use_dq2) {                                                                                                      \
             GG_TRY(set_smem(&attn_bwd_dq2_kernel<D, B>, sm2));                                                              \
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<D, B>), grid, dim3(256), sm2, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
