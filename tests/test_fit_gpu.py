@@ -57,3 +57,29 @@ def test_fit_two_epochs_checkpoints_and_reload(tmp_path, precision):
     da = w.disc(x, patches, ppad, text, tpad)
     db = w2.disc(x, patches, ppad, text, tpad)
     assert torch.allclose(da, db, rtol=1e-5, atol=1e-6)
+
+
+def test_fit_from_the_device_resident_loader(tmp_path):
+    """gemm_gan_amd/data.py: the reference's on-disk case files -> HBM-resident cache -> minibatches assembled on the device in
+    the reference loader's tuple order -> WGAN_GP.fit, unchanged."""
+    from gemm_gan_amd.data import DeviceCaseCache
+    rng = np.random.default_rng(0)
+    G, Lz, E, H, Dt, Dp, T, P = 90, 16, 64, 32, 24, 40, 6, 12
+    pdir, tdir = tmp_path / "patches", tmp_path / "tokens"
+    pdir.mkdir(); tdir.mkdir()
+    ids = []
+    for i, n in enumerate([5, 30, 12, 40, 7, 19, 3, 25, 14]):
+        cid = f"c{i}"
+        np.save(pdir / f"{cid}.npy", rng.standard_normal((n, Dp)))
+        np.save(tdir / f"{cid}.npy", rng.standard_normal((1, T, Dt)).astype(np.float32))
+        m = np.ones((1, T), dtype=np.int64); m[0, T - (i % 3):] = 0
+        np.save(tdir / f"{cid}_attention_mask.npy", m)
+        ids.append(cid)
+    cache = DeviceCaseCache(ids, tdir, pdir, rng.standard_normal((len(ids), G)), num_patches=P, device="cuda:0")
+    loader = cache.loader(batch_size=4, shuffle=True, seed=1)
+    b = next(iter(loader))
+    assert all(t.is_cuda for t in b) and b[3].shape == (4, P, Dp) and b[4].dtype == torch.bool
+    w = gga.WGAN_GP(G, Lz, E, [H, H, G], [H, H, 1], text_embedding_dims=Dt, patches_embedding_dims=Dp, n_critic=2, dropout=0.1,
+                    seed=2, device="cuda:0", results_dire="")
+    hist = w.fit(loader, epochs=2)
+    assert len(hist["d loss"]) == 2 and all(np.isfinite(v) for v in hist["d loss"] + hist["g loss"])
