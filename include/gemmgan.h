@@ -197,6 +197,15 @@ int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* 
 /* counters of the last gg_train_step / iteration: kernels launched */
 int64_t gg_launch_count(const gg_engine* e);
 
+/* ---- evaluation: nearest reference records ---------------------------------------------
+ * The device-side math of the reference's privacy metrics DCR / NNDR (src/privacy_evaluator.py:9-66): for every query row
+ * the Euclidean distance to its nearest (d1) and second nearest (d2, +inf if nr == 1) row of `refs`, exact fp32 differences.
+ * queries [nq, dim], refs [nr, dim] row-major device pointers; scratch: gg_eval_nn2_scratch(nq, nr) floats.
+ * Independent of gg_engine. */
+long gg_eval_nn2_scratch(long nq, long nr);
+int gg_eval_nn2(const float* queries, long nq, const float* refs, long nr, int dim, float* d1, float* d2, float* scratch,
+                long scratch_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
