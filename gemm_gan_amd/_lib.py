@@ -72,6 +72,11 @@ SYMBOLS = {
     "gg_reset_optimizer_steps": (C.c_int, [C.c_void_p]),
     "gg_get_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gg_eval_knn_scratch": (C.c_long, [C.c_long, C.c_long, C.c_int]),
+    "gg_eval_knn_width": (C.c_int, [C.c_int]),
+    "gg_eval_knn": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "gg_eval_prdc_counts": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "gg_eval_nn2_scratch": (C.c_long, [C.c_long, C.c_long]),
     "gg_eval_nn2": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "gg_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,

@@ -202,6 +202,16 @@ int64_t gg_launch_count(const gg_engine* e);
  * the Euclidean distance to its nearest (d1) and second nearest (d2, +inf if nr == 1) row of `refs`, exact fp32 differences.
  * queries [nq, dim], refs [nr, dim] row-major device pointers; scratch: gg_eval_nn2_scratch(nq, nr) floats.
  * Independent of gg_engine. */
+/* PRDC (src/distribution_distances.py:87-142; the reference uses L1 distances there, :64): the k smallest distances of every
+ * query row to `refs`, ascending, out [nq, gg_eval_knn_width(k)] (1 <= k <= 16; l1 != 0: sum |q - r|, else Euclidean); and
+ * the counting pass over the never-materialised [real x fake] distance matrix: below_real[j] = #{i: d_ij < rad_real[i]},
+ * any_fake[i] = any_j d_ij < rad_fake[j], min_d[i] = min_j d_ij. */
+long gg_eval_knn_scratch(long nq, long nr, int k);
+int gg_eval_knn_width(int k);
+int gg_eval_knn(const float* queries, long nq, const float* refs, long nr, int dim, int k, int l1, float* out, float* scratch,
+                long scratch_floats, void* stream);
+int gg_eval_prdc_counts(const float* real, long nr, const float* fake, long nf, int dim, int l1, const float* rad_real,
+                        const float* rad_fake, int* below_real, int* any_fake, float* min_d, void* stream);
 long gg_eval_nn2_scratch(long nq, long nr);
 int gg_eval_nn2(const float* queries, long nq, const float* refs, long nr, int dim, float* d1, float* d2, float* scratch,
                 long scratch_floats, void* stream);

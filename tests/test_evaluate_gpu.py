@@ -47,3 +47,31 @@ def test_single_reference_row_and_bad_arguments():
         evaluate.nearest2(q, torch.randn(4, 7).cuda())
     with pytest.raises(RuntimeError):
         evaluate.nearest2(q.cpu(), q.cpu())
+
+
+def _ref_prdc(real, fake, k):
+    """src/distribution_distances.py:87-142 restated with scipy (L1 distances, float64)."""
+    from scipy.spatial.distance import cdist
+    def radii(x):
+        d = cdist(x, x, "cityblock")
+        return np.sort(d, axis=1)[:, k]                       # get_kth_value(d, k + 1): the (k+1)-th smallest incl. the 0 of the sample itself
+    rr, rf = radii(real), radii(fake)
+    d = cdist(real, fake, "cityblock")
+    return dict(precision=(d < rr[:, None]).any(axis=0).mean(), recall=(d < rf[None, :]).any(axis=1).mean(),
+                density=(1.0 / k) * (d < rr[:, None]).sum(axis=0).mean(), coverage=(d.min(axis=1) < rr).mean()), rr
+
+
+@pytest.mark.parametrize("shape,k", [((150, 97, 33), 5), ((64, 200, 130), 3), ((300, 310, 700), 10), ((40, 33, 20), 15)])
+def test_prdc_matches_the_reference_arithmetic(shape, k):
+    nr, nf, dim = shape
+    rng = np.random.default_rng(nr + k)
+    real = rng.standard_normal((nr, dim))
+    fake = 0.8 * rng.standard_normal((nf, dim)) + 0.3          # overlapping, not identical manifolds: every metric strictly inside (0, 1)
+    ref, rr = _ref_prdc(real, fake, k)
+    radii = evaluate.kth_smallest(torch.tensor(real, dtype=torch.float32).cuda(), torch.tensor(real, dtype=torch.float32).cuda(), k + 1)
+    assert radii[:, 0].abs().max().item() < 1e-4                                       # the sample itself
+    assert np.allclose(radii[:, k].cpu().numpy(), rr, rtol=2e-5)
+    got = evaluate.compute_prdc(real, fake, k)
+    tol = 2.5 / min(nr, nf)                                      # a comparison at a float32 / float64 tie may fall either way
+    for name in ("precision", "recall", "density", "coverage"):
+        assert abs(got[name] - ref[name]) <= tol * max(1.0, ref[name]), (name, got[name], ref[name])

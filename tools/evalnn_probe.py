@@ -26,3 +26,11 @@ for i in range(0, nq, 128):                      # the reference's batching (src
 ref = torch.cat(outs)
 torch.cuda.synchronize()
 print(f"reference expression (torch, same GPU): {(time.perf_counter() - t0) * 1e3:.1f} ms; max |d1 - ref| = {(d1 - ref).abs().max().item():.2e}")
+for _ in range(2):
+    r = evaluate.compute_prdc(real, gen, 5)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+r = evaluate.compute_prdc(real, gen, 5)
+torch.cuda.synchronize()
+print(f"compute_prdc [{nr} real x {nq} fake x {dim}], k = 5 (two k-NN radius passes + one counting pass, L1): "
+      f"{(time.perf_counter() - t0) * 1e3:.1f} ms  {r}")
