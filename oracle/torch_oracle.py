@@ -17,6 +17,10 @@ conditional_gan_cross_attention_with_film.py unless another file is named):
                             ``train_gen`` (:425-461), ``train`` (:463-477), with z / alpha
                             supplied explicitly so that a step is a pure function of its inputs.
 
+Sibling files (``PathConfig.variant``, each pinned by its own fixtures): ``film`` = src/conditional_gan_film.py
+(``film_config``), ``img`` = src/conditional_gan_img_transformer.py (``img_config``), ``vanilla`` =
+src/vanilla_gan_unconditional.py (``vanilla_config``).
+
 The arithmetic of the reference lives in stock ``torch.nn`` modules (SURVEY.md section 8 row a14);
 the oracle therefore composes the same stock modules under the same attribute names, so a
 reference ``state_dict`` loads with ``strict=True`` (including the dead
