@@ -988,6 +988,16 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->s_dkv, 2 * E, w + n.t2i.inw + (long)E * E, E, e->sdx, E, (int)(RB * S), 2 * E, E)));
         }
     }
+    if (i2t_sh) {
+        // With shared text keys the token gradient is complete here ([B*T, E] from the I2T projection + the T2I query rows):
+        // the text encoder's parameter gradients are leaves - on the side stream, beside the encoder layers' backward
+        KL(k_fold_rows_add(e->s_dtokrep, (long)T * E, e->s_dtok0, B, Rb, E, c.st));
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->s_dtokrep, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
+        GG_TRY(k_colsum(e->s_dtokrep, (long)B * T, E, E, g + n.te_b, cs.st)); e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
     }   // xattn
     // ---- encoder layers, last to first ---------------------------------------------------------------
     float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
@@ -1121,7 +1131,6 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         dx0 = e->s_dx0;
         if (!i2t_sh) dtok = e->s_dtok;
     }
-    if (i2t_sh) KL(k_fold_rows_add(e->s_dtokrep, (long)T * E, e->s_dtok0, B, Rb, E, c.st));      // + the T2I query rows (token 0)
     KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
     KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
     if (e->pe_ln) {
@@ -1165,7 +1174,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     KL(k_film_act_bwd(e->s_dgb, a.gb, a.gbpre, B, Dp, c.st));
     GG_TRY(lin_bwd_weight(c, e->s_dgb, 2 * Dp, in->text, (long)T * Dt, g + n.film_w, Dt, B, 2 * Dp, Dt));
     KL(k_colsum(e->s_dgb, B, 2 * Dp, 2 * Dp, g + n.film_b, c.st));
-    if (e->xattn) {
+    if (e->xattn && !i2t_sh) {
         GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
         KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
     }
