@@ -170,7 +170,7 @@ struct gg_engine {
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
-    float *s_dt, *s_dp, *s_dq, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
+    float *s_dt, *s_dp, *s_dq, *s_dq2, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
     // live profiling
     bool prof_on = false;
@@ -377,7 +377,7 @@ size_t carve(gg_engine* e, void* base) {
     e->sdres = a.take<float>(Rb * S * E);
     e->sdctx = a.take<float>(Rb * S * E);
     e->sdh = a.take<float>(Rb * S * F);
-    e->s_dt = a.take<float>(Rb * E); e->s_dp = a.take<float>(Rb * E); e->s_dq = a.take<float>(Rb * E);
+    e->s_dt = a.take<float>(Rb * E); e->s_dp = a.take<float>(Rb * E); e->s_dq = a.take<float>(Rb * E); e->s_dq2 = a.take<float>(Rb * E);   // I2T / T2I query gradients: separate, the side-stream leaves read them late
     e->s_tmpE = a.take<float>(Rb * E);
     e->s_dkv = a.take<float>(Rb * S * 2 * E);
     e->s_dkv2 = a.take<float>(Rb * T * 2 * E);
@@ -948,12 +948,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             v.M = (int)RB; v.N = dh; v.K = E; v.batch = nh; v.batch_inner = 1;
             v.A = e->s_dqt; v.lda = (long)nh * E; v.layA = LAY_KC; v.sAo = E;
             v.B = w + n.t2i.inw + (long)E * E; v.ldb = E; v.layB = LAY_KC; v.sBo = (long)dh * E;
-            v.C = e->s_dq; v.ldc = E; v.sCo = dh;
-            GG_TRY(side_wait(c, 3));              // the I2T in-projection gradient on the side stream still reads the first s_dq
+            v.C = e->s_dq2; v.ldc = E; v.sCo = dh;
             GG_TRY(run_gemm(c, v));
         } else {
-            GG_TRY(side_wait(c, 3));
-            KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq, e->s_dqt, (int)RB, S, E, nh, c.st));
+            KL(sqx_attn_bwd(e->s_tmpE, a.t2i_q, enc, w + n.t2i.inw, a.t2i_P, e->sdx, e->s_dq2, e->s_dqt, (int)RB, S, E, nh, c.st));
         }
         {   // dWk_h += q_h (x) dqt_h  and  dWv_h += dctx_h (x) xbar_h, summed over the batch (per-head small GEMMs); leaves
             Ctx cs = c;
@@ -966,19 +964,18 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             p.A = e->s_tmpE; p.B = a.t2i_xbar; p.C = g + n.t2i.inw + 2L * E * E;
             GG_TRY(run_gemm(cs, p));
             GG_TRY(k_colsum(e->s_tmpE, RB, E, E, g + n.t2i.inb + 2 * E, cs.st)); e->launches++;         // d(bv) = sum dctx ; d(bk) == 0
-            GG_TRY(lin_bwd_weight(cs, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
-            GG_TRY(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, cs.st)); e->launches++;
+            GG_TRY(lin_bwd_weight(cs, e->s_dq2, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+            GG_TRY(k_colsum(e->s_dq2, RB, E, E, g + n.t2i.inb, cs.st)); e->launches++;
             GG_TRY(side_end(c, fk, 3));
         }
-        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
-        else GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq2, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
+        else GG_TRY(lin_bwd_data(c, e->s_dq2, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
     } else {
-        GG_TRY(side_wait(c, 3));                  // s_dq is rewritten: the I2T in-projection gradient on the side stream reads it
-        KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq, e->s_dkv, (int)RB, S, E, nh, c.st));
-        GG_TRY(lin_bwd_weight(c, e->s_dq, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
-        KL(k_colsum(e->s_dq, RB, E, E, g + n.t2i.inb, c.st));
-        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
-        else GG_TRY(lin_bwd_data(c, e->s_dq, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
+        KL(k_sq_attn_bwd(e->s_tmpE, a.t2i_q, a.t2i_kv, a.t2i_P, e->s_dq2, e->s_dkv, (int)RB, S, E, nh, c.st));
+        GG_TRY(lin_bwd_weight(c, e->s_dq2, E, tok, (long)T * E, g + n.t2i.inw, E, (int)RB, E, E));
+        KL(k_colsum(e->s_dq2, RB, E, E, g + n.t2i.inb, c.st));
+        if (i2t_sh) GG_TRY(lin_bwd_data(c, e->s_dq2, E, w + n.t2i.inw, E, e->s_dtok0, E, (int)RB, E, E));
+        else GG_TRY(lin_bwd_data(c, e->s_dq2, E, w + n.t2i.inw, E, e->s_dtokrep, (long)T * E, (int)RB, E, E, 1));
         GG_TRY(lin_bwd_weight(c, e->s_dkv, 2 * E, enc, E, g + n.t2i.inw + (long)E * E, E, (int)(RB * S), 2 * E, E));
         KL(k_colsum(e->s_dkv, RB * S, 2 * E, 2 * E, g + n.t2i.inb + E, c.st));
         {   // denc = dkv Wkv : reduction over the 2E projected features, W^T = columns E..3E of in_proj^T

@@ -9,9 +9,10 @@ def nm(r):
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first_f32 = next((i for i, r in enumerate(rows) if "gemm_f32_kernel" in r["Kernel_Name"]), len(rows))
 bf = rows[:first_f32]
-t_end = max(int(r["End_Timestamp"]) for r in bf)
+eng = [r for r in bf if any(k in r["Kernel_Name"] for k in ("tlin_", "attn_", "wgrad_", "gemm_small"))] or bf
+t_end = max(int(r["End_Timestamp"]) for r in eng)            # the last engine kernel: host-side epilogue work is not a step
 t0 = t_end - int(steps * ms * 1e6)
-win = [r for r in bf if int(r["Start_Timestamp"]) >= t0]
+win = [r for r in bf if t0 <= int(r["Start_Timestamp"]) <= t_end]
 by = collections.defaultdict(list)
 for r in win: by[r["Stream_Id"]].append(r)
 print("window %.2f ms, %d dispatches" % ((t_end - t0) / 1e6, len(win)))
