@@ -41,6 +41,9 @@ CASES = {
     # the same at the production head width (dh = 64), several query groups of the long dQ kernel (18 query tiles > 12)
     "long_S545_E256": dict(cfg=PathConfig(n_genes=48, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=24,
                                            patch_dims=32, dropout=0.0), B=2, P=544, T=1),
+    # the longest sequence the key-streaming kernels take (64 key tiles), ragged tail
+    "long_S2047": dict(cfg=PathConfig(n_genes=40, latent_dims=8, embedding_dims=64, hidden_dims=16, text_dims=16,
+                                      patch_dims=24, dropout=0.0), B=1, P=2046, T=1),
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
@@ -245,7 +248,7 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256"])
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256", "long_S2047"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_flash_attention_matches_unfused_path(case, dropout):
     """Fused attention forward/backward (attention.hip) against the unfused bf16 path (GEMM + softmax +
