@@ -52,6 +52,13 @@ SYMBOLS = {
     "gg_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "gg_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_int, C.c_void_p]),
     "gg_critic_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
+    "gg_critic_backward_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
+    "gg_critic_backward_cond": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
+    "gg_critic_cond_prefetch": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
+    "gg_mlp_grad_range": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gg_gradient_penalty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_int, C.c_void_p, C.c_void_p]),
+    "gg_generator_backward_head": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
+    "gg_generator_backward_cond": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
     "gg_critic_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "gg_generator_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
     "gg_generator_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),

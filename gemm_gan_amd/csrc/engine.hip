@@ -141,6 +141,10 @@ struct gg_engine {
     float *X2;                 // [2B, G]: fake rows then real rows
     float *Xpre = nullptr;     // [GG_MAX_PREFETCH, B, G]: generator outputs of a whole train() computed in batched passes
     int pre_n = 0, pre_next = 0, pre_B = 0;
+    // critic conditioning pass computed ahead (gg_critic_cond_prefetch): valid until the critic's weights or actsD change
+    bool dcond_valid = false;
+    int dcond_B = 0, dcond_P = 0, dcond_T = 0, dcond_R = 0;
+    int crit_R = 0;            // replicas of the critic iteration in flight (between its head and conditioning phases)
     // pipelined prefetch: all but the first output are computed on a third stream in their own activation arena, beside
     // the critic iterations that do not need them yet; pre_ev[k] marks output k ready (pre_wait[k]: not yet waited for)
     hipStream_t pre_stream = nullptr;
@@ -1272,13 +1276,53 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
     return 0;
 }
 
-int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses,
-                    const float* x_fake_pre = nullptr) {      // x_fake_pre: generator output computed ahead (its bf16 shadow
+// Gradient penalty of the B interpolate rows whose head activations are a1h / a2h (R:351-374) and, if `backward`, its
+// double backward into dW1x, dW2, dw3 (the only parameters it reaches).  *gp_loss += the penalty.
+int gp_chain(Ctx& c, Net& D, const float* a1h, const float* a2h, int B, float* gp_loss, bool backward) {
+    gg_engine* e = c.e;
+    const int G = e->G, E = e->E, H = e->H;
+    const float slope = e->cfg.negative_slope;
+    KL(k_gp_front(a1h, a2h, D.w + D.w3, D.w + D.w2, e->gp_g1, e->gp_dg1, e->gp_nrm2, B, H, slope, c.st));   // g1 = m1 * ((m2*w3) W2)
+    KL(k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, c.st));                       // grad = g1 W1x, |grad|^2
+    KL(k_gp_coef_scale(e->gp_nrm2, e->gp_g1, e->gp_coef, backward ? e->gp_g1s : nullptr, gp_loss, B, H,
+                       e->cfg.gp_weight, c.st));
+    if (!backward) return 0;
+    {
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(lin_bwd_weight(cs, e->gp_g1s, H, e->gp_grad, G, D.g + D.w1, G + E, B, H, G));    // dW1x += (coef g1)^T grad
+        GG_TRY(side_end(c, fk, 3));
+    }
+    {   // dg1pre += grad W1x^T : split over the gene dimension, atomics into the buffer gp_front zeroed
+        GemmP p;
+        p.A = e->gp_grad; p.B = D.w + D.w1; p.C = e->gp_dg1; p.M = B; p.N = H; p.K = G; p.lda = G; p.ldb = G + E; p.ldc = H;
+        p.layA = LAY_KC; p.layB = LAY_KC;
+        const long tiles = tiles_of(B, H);
+        p.splitk = (int)std::max<long>(2, std::min<long>((G + 255) / 256, std::max<long>(1, 256 / tiles)));
+        // exact fp32 in both modes (see gpchain.hip)
+        e->launches++;
+        GG_TRY(gemm_f32(p, c.st));
+    }
+    {   // dW2, dw3: on the side stream like the head's own dW2 / dW3 (they add into the same gradient slots)
+        Ctx cs = c;
+        const bool fk = side_begin(c, cs);
+        GG_TRY(k_gp_tail(e->gp_dg1, e->gp_coef, a1h, a2h, D.w + D.w3, D.w + D.w2, D.g + D.w2, D.g + D.w3, B, H, slope, cs.st));
+        e->launches++;
+        GG_TRY(side_end(c, fk, 3));
+    }
+    return 0;
+}
+
+// critic conditioning forward computed ahead of the iteration that uses it (gg_critic_cond_prefetch): valid while the critic's
+// weights and the minibatch are unchanged
+// One critic iteration up to its optimiser step, in two phases so that a data-parallel host can start the all-reduce of the
+// MLP-head gradients (complete after the head phase) under the conditioning stack's backward (the cond phase).
+int critic_head_phase(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses,
+                      const float* x_fake_pre = nullptr) {      // x_fake_pre: generator output computed ahead (its bf16 shadow
                                                               // weights were refreshed then and the generator is not run here)
     gg_engine* e = c.e;
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H;
-    const float slope = e->cfg.negative_slope;
     const int R = e->dropout > 0.f ? 3 : 1;
     GG_REQUIRE(R <= e->maxR, "workspace was sized for dropout == 0; recreate the engine with dropout > 0");
     if (!x_fake_pre) GG_TRY(refresh_shadows(c, e->net[GG_ROLE_GENERATOR]));
@@ -1290,7 +1334,12 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     else GG_TRY(generator_forward(c, z, in, e->X2, 1, 0));
     KL(k_copy(e->X2 + (long)B * G, x_real, (long)B * G, c.st));
     // critic conditioning: R independent dropout replicas (fake, real, interpolate) R:403,404,360
-    GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
+    {
+        const bool have = e->dcond_valid && e->dcond_B == B && e->dcond_P == in->P && e->dcond_T == in->T && e->dcond_R == R;
+        e->dcond_valid = false;
+        if (!have) GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
+    }
+    e->crit_R = R;
     if (R == 1) KL(k_copy_rows_bcast(e->c3, e->actsD.c, 3L * B, B, E, c.st));
     else KL(k_copy(e->c3, e->actsD.c, 3L * B * E, c.st));
     // first layer, gene part, for fake and real rows at once; the interpolate's is their lerp
@@ -1304,40 +1353,18 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
     // sums cancel exactly, R:43-45); summing the 2B seeds in one pass would leave ~1e-8 of rounding that
     // RMSprop/Adam normalise into a +-O(lr) drift of the critic's output offset, so it is not computed.
     GG_TRY(head_backward(c, D, e->dseed, e->X2, e->c3, e->headD.a1, e->headD.a2, 2 * B, true, e->dc, nullptr, false));
-    // ---- gradient penalty, closed form on the interpolate rows -------------------------
-    const float* a1h = e->headD.a1 + 2L * B * H;
-    const float* a2h = e->headD.a2 + 2L * B * H;
-    KL(k_mask_times_vec(e->gp_g2, a2h, D.w + D.w3, B, H, slope, c.st));                    // g2 = m2 * w3
-    GG_TRY(lin_bwd_data(c, e->gp_g2, H, D.w + D.w2, H, e->gp_g1, H, B, H, H));           // u = g2 W2
-    KL(k_act_bwd(e->gp_g1, a1h, (long)B * H, slope, 1.f, c.st));                           // g1 = m1 * u
-    GG_TRY(lin_bwd_data(c, e->gp_g1, H, D.w + D.w1, G + E, e->gp_grad, G, B, H, G));     // grad = g1 W1x
-    KL(k_row_sumsq(e->gp_grad, e->gp_nrm2, B, G, c.st));
-    KL(k_gp_coef(e->gp_nrm2, e->gp_coef, losses, B, e->cfg.gp_weight, c.st));
-    KL(k_copy(e->gp_g1s, e->gp_g1, (long)B * H, c.st));
-    KL(k_rowscale(e->gp_g1s, e->gp_coef, B, H, c.st));
-    {
-        Ctx cs = c;
-        const bool fk = side_begin(c, cs);
-        GG_TRY(lin_bwd_weight(cs, e->gp_g1s, H, e->gp_grad, G, D.g + D.w1, G + E, B, H, G));    // dW1x += (coef g1)^T grad
-        GG_TRY(side_end(c, fk, 3));
-    }
-    GG_TRY(lin_fwd(c, e->gp_grad, G, D.w + D.w1, G + E, nullptr, e->gp_dg1, H, B, H, G)); // grad W1x^T
-    KL(k_rowscale(e->gp_dg1, e->gp_coef, B, H, c.st));                                     // dg1 = s W1x^T
-    KL(k_act_bwd(e->gp_dg1, a1h, (long)B * H, slope, 1.f, c.st));                          // du = m1 * dg1
-    {
-        Ctx cs = c;
-        const bool fk = side_begin(c, cs);
-        GG_TRY(lin_bwd_weight(cs, e->gp_g2, H, e->gp_dg1, H, D.g + D.w2, H, B, H, H));         // dW2 += g2^T du
-        GG_TRY(side_end(c, fk, 3));
-    }
-    GG_TRY(lin_fwd(c, e->gp_dg1, H, D.w + D.w2, H, nullptr, e->gp_dg2, H, B, H, H));     // dg2 = du W2^T
-    {   // dw3 += sum m2*dg2 : on the side stream like the head's own dW3 (two streams must not add into one gradient)
-        Ctx cs = c;
-        const bool fk = side_begin(c, cs);
-        GG_TRY(k_colsum_masked(e->gp_dg2, a2h, B, H, slope, D.g + D.w3, cs.st)); e->launches++;
-        GG_TRY(side_end(c, fk, 3));
-    }
-    // ---- conditioning backward for the rows that carry gradient --------------------------------------
+    // ---- gradient penalty, closed form on the interpolate rows: gpchain.hip, six launches -------------
+    GG_TRY(gp_chain(c, D, e->headD.a1 + 2L * B * H, e->headD.a2 + 2L * B * H, B, losses + GG_LOSS_GP, true));
+    return 0;
+}
+// conditioning backward for the rows that carry gradient (second phase of the critic iteration)
+int critic_cond_phase(Ctx& c, const gg_cond* in) {
+    gg_engine* e = c.e;
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int B = in->B, E = e->E;
+    const int R = e->crit_R;
+    GG_REQUIRE(R == 1 || R == 3, "gg_critic_backward_cond without a preceding gg_critic_backward_head");
+    e->crit_R = 0;
     if (R == 1) {
         KL(k_axpy(e->dc, e->dc + (long)B * E, 1.f, (long)B * E, c.st));
         GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 1));
@@ -1345,6 +1372,12 @@ int critic_backward(Ctx& c, const float* x_real, const float* z, const float* al
         GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 2));
     }
     return 0;
+}
+
+int critic_backward(Ctx& c, const float* x_real, const float* z, const float* alpha, const gg_cond* in, float* losses,
+                    const float* x_fake_pre = nullptr) {
+    GG_TRY(critic_head_phase(c, x_real, z, alpha, in, losses, x_fake_pre));
+    return critic_cond_phase(c, in);
 }
 
 // The generator is frozen during the n_critic critic iterations of a train() (R:463-477) and the conditioning batch is
@@ -1392,6 +1425,9 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
     // their own arena while the critic iterations that do not need them yet proceed.
     static const bool pipe_off = getenv("GG_NO_PREFETCH_PIPE") != nullptr;
     bool pipe = !pipe_off && n > 1 && e->side_on && e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(in->P + 1, e->E, e->nh);
+    // a critic conditioning pass computed ahead lives in the critic's arena: the generator passes take the spare one, in order
+    const bool spare = e->dcond_valid;
+    if (spare) pipe = false;
     if (pipe && !e->pre_stream) {
         bool ok = create_side_stream(&e->pre_stream);
         ok = ok && hipEventCreateWithFlags(&e->pre_fork, hipEventDisableTiming) == hipSuccess;
@@ -1401,7 +1437,8 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
     if (!pipe) {
         for (int done = 0; done < n;) {
             const int r = std::min(n - done, rmax);
-            GG_TRY(prefetch_chunk(c, z_all, done, r, in, e->actsD, e->headD, e->c3));
+            if (spare) GG_TRY(prefetch_chunk(c, z_all, done, r, in, e->actsP, e->headP, e->c3P));
+            else GG_TRY(prefetch_chunk(c, z_all, done, r, in, e->actsD, e->headD, e->c3));
             done += r;
         }
         e->pre_n = n;
@@ -1435,12 +1472,13 @@ inline const float* next_prefetched(Ctx& c, int B) {
     return e->Xpre + (long)k * B * e->G;
 }
 
-int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
+int generator_head_phase(Ctx& c, const float* z, const gg_cond* in, float* losses) {
     gg_engine* e = c.e;
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, G = e->G, E = e->E, H = e->H, L = e->L;
     GG_TRY(prefetch_drain(c));                     // passes of the frozen generator still in flight read its weights / shadows
+    e->dcond_valid = false;                        // the frozen critic's forward below takes the critic's arena
     GG_TRY(refresh_shadows(c, Gn));
     GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses + GG_LOSS_G, 1, 0.f, c.st));
@@ -1465,7 +1503,47 @@ int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses)
     GG_TRY(head_backward(c, D, e->dseed, nullptr, nullptr, e->headD.a1, e->headD.a2, B, false, nullptr, e->dxfake));
     GG_TRY(head_backward(c, Gn, e->dxfake, z, e->actsG.c, e->headG.a1, e->headG.a2, B, true, e->dc, nullptr));
     (void)L;
-    GG_TRY(cond_backward(c, Gn, in, e->actsG, e->dc, 1));
+    return 0;
+}
+int generator_cond_phase(Ctx& c, const gg_cond* in) {
+    gg_engine* e = c.e;
+    return cond_backward(c, e->net[GG_ROLE_GENERATOR], in, e->actsG, e->dc, 1);
+}
+int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
+    GG_TRY(generator_head_phase(c, z, in, losses));
+    return generator_cond_phase(c, in);
+}
+
+// WGAN_GP.gradient_penalty (R:351-374) as a call of its own: the penalty of the interpolates alpha*real + (1-alpha)*fake
+// under the critic's current weights; no gradient is written.  *gp_out = mean((|grad_x^ D(x^)| - 1)^2).
+int gradient_penalty(Ctx& c, const float* x_real, const float* x_fake, const float* alpha, const gg_cond* in, int train, float* gp_out) {
+    gg_engine* e = c.e;
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int B = in->B, G = e->G, E = e->E, H = e->H;
+    e->dcond_valid = false;
+    GG_TRY(refresh_shadows(c, D));
+    KL(k_copy(e->X2, x_fake, (long)B * G, c.st));
+    KL(k_copy(e->X2 + (long)B * G, x_real, (long)B * G, c.st));
+    GG_TRY(cond_forward(c, D, in, e->actsD, 1, train ? e->dropout : 0.f, 0));
+    // first layer of the interpolate rows by linearity: x^ W1x^T = alpha (x W1x^T) + (1-alpha) (x~ W1x^T)
+    GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->Pfr, H, 2 * B, H, G));
+    KL(k_lerp_rows(e->Pfr, alpha, e->headD.a1, B, H, c.st));
+    GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, nullptr, 1, B, 0));
+    KL(k_fill(gp_out, 1, 0.f, c.st));
+    return gp_chain(c, D, e->headD.a1, e->headD.a2, B, gp_out, false);
+}
+
+// The critic's conditioning pass of the NEXT critic iteration (its R dropout replicas), ahead of time: it depends on the
+// critic's weights and the minibatch only, so a data-parallel host runs it under the generator's gradient all-reduce.
+int critic_cond_prefetch(Ctx& c, const gg_cond* in) {
+    gg_engine* e = c.e;
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int R = e->dropout > 0.f ? 3 : 1;
+    GG_REQUIRE(R <= e->maxR, "workspace was sized for dropout == 0; recreate the engine with dropout > 0");
+    GG_TRY(refresh_shadows(c, D));
+    GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
+    e->dcond_valid = true;
+    e->dcond_B = in->B; e->dcond_P = in->P; e->dcond_T = in->T; e->dcond_R = R;
     return 0;
 }
 
@@ -1577,6 +1655,7 @@ int gg_forward(gg_engine* e, int role, const float* v, const gg_cond* in, float*
     Ctx c{e, (hipStream_t)stream};
     GG_TRY(refresh_shadows(c, e->net[role]));
     if (role == GG_ROLE_GENERATOR) return generator_forward(c, v, in, out, train);
+    e->dcond_valid = false;
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B;
     GG_TRY(cond_forward(c, D, in, e->actsD, 1, train ? e->dropout : 0.f));
@@ -1592,6 +1671,53 @@ int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const 
     Ctx c{e, (hipStream_t)stream};
     return critic_backward(c, x_real, z, alpha, in, losses, next_prefetched(c, in->B));
 }
+int gg_critic_backward_head(gg_engine* e, const float* x_real, const float* z, const float* alpha, const gg_cond* in,
+                            float* losses, void* stream) {
+    GG_REQUIRE(e && x_real && z && alpha && losses, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    GG_TRY(critic_head_phase(c, x_real, z, alpha, in, losses, next_prefetched(c, in->B)));
+    return side_wait(c, 3);       // the MLP-head gradient slots are complete on the caller's stream
+}
+int gg_critic_backward_cond(gg_engine* e, const gg_cond* in, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return critic_cond_phase(c, in);
+}
+int gg_critic_cond_prefetch(gg_engine* e, const gg_cond* in, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return critic_cond_prefetch(c, in);
+}
+int gg_gradient_penalty(gg_engine* e, const float* x_real, const float* x_fake, const float* alpha, const gg_cond* in, int train,
+                        float* gp_out, void* stream) {
+    GG_REQUIRE(e && x_real && x_fake && alpha && gp_out, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return gradient_penalty(c, x_real, x_fake, alpha, in, train, gp_out);
+}
+int gg_generator_backward_head(gg_engine* e, const float* z, const gg_cond* in, float* losses, void* stream) {
+    GG_REQUIRE(e && z && losses, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    GG_TRY(generator_head_phase(c, z, in, losses));
+    return side_wait(c, 3);
+}
+int gg_generator_backward_cond(gg_engine* e, const gg_cond* in, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    return generator_cond_phase(c, in);
+}
+int gg_mlp_grad_range(const gg_engine* e, int role, int64_t* offset, int64_t* numel) {
+    GG_REQUIRE(e && (role == 0 || role == 1) && offset && numel, "bad argument");
+    const Net& n = e->net[role];
+    *offset = n.w1;
+    *numel = n.live - n.w1;
+    return 0;
+}
 int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond* in, void* stream) {
     GG_REQUIRE(e && z_all && n >= 0, "bad argument");
     GG_TRY(check_cond(e, in));
@@ -1601,6 +1727,7 @@ int gg_generator_prefetch(gg_engine* e, const float* z_all, int n, const gg_cond
 int gg_critic_apply(gg_engine* e, float grad_scale, void* stream) {
     GG_REQUIRE(e, "null argument");
     Ctx c{e, (hipStream_t)stream};
+    e->dcond_valid = false;
     return apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, grad_scale);
 }
 int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* in, float* losses, void* stream) {
@@ -1628,6 +1755,7 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const fl
     if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in));
     for (int k = 0; k < n_critic; ++k) {
         GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(c, in->B)));
+        e->dcond_valid = false;
         GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
     }
     e->pre_n = e->pre_next = 0;

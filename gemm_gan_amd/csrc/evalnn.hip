@@ -218,7 +218,7 @@ __global__ void topk_merge_kernel(const float* __restrict__ part, long nq, int s
 //   below_real[j] = #{i : d_ij < rad_real[i]}   (precision: > 0; density: mean / k)
 //   any_fake[i]   = any_j d_ij < rad_fake[j]     (recall)
 //   min_d[i]      = min_j d_ij                   (coverage: < rad_real[i]); stored as the float's bit pattern (d >= 0)
-template <bool L1>
+template <bool L1, bool INC>
 __global__ __launch_bounds__(NTH) void prdc_kernel(const float* __restrict__ real, long nr, const float* __restrict__ fake, long nf, int dim,
                                                     const float* __restrict__ rad_real, const float* __restrict__ rad_fake,
                                                     int* __restrict__ below_real, int* __restrict__ any_fake, unsigned* __restrict__ min_d) {
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(NTH) void prdc_kernel(const float* __restrict__ rea
             const long fj = j0 + 4 * tx + j;
             if (fj >= nf) continue;
             const float d = L1 ? acc[i][j] : sqrtf(acc[i][j]);
-            if (d < rr) atomicAdd(&colcnt[4 * tx + j], 1);
-            any |= d < rad_fake[fj];
+            if (INC ? d <= rr : d < rr) atomicAdd(&colcnt[4 * tx + j], 1);
+            any |= INC ? d <= rad_fake[fj] : d < rad_fake[fj];
             mn = fminf(mn, d);
         }
         if (any) atomicOr(&rowany[4 * ty + i], 1);
@@ -310,8 +310,15 @@ int prdc_counts(const float* real, long nr, const float* fake, long nf, int dim,
     GG_CHECK_HIP(hipMemsetAsync(any_fake, 0, sizeof(int) * nr, st));
     GG_CHECK_HIP(hipMemsetAsync(min_d, 0x7f, sizeof(float) * nr, st));            // 0x7f7f7f7f: a huge finite float, any distance is below
     const dim3 grid((unsigned)((nr + TQ - 1) / TQ), (unsigned)((nf + TR - 1) / TR));
-    if (l1) prdc_kernel<true><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, reinterpret_cast<unsigned*>(min_d));
-    else prdc_kernel<false><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, reinterpret_cast<unsigned*>(min_d));
+    // l1 bit 0: L1 distances (PRDC, src/distribution_distances.py:64), else Euclidean; bit 1: inclusive comparisons d <= radius
+    // (ManifoldEstimator.evaluate, src/unsupervised_metrics.py:223) instead of d < radius (compute_prdc, :121-139)
+    unsigned* md = reinterpret_cast<unsigned*>(min_d);
+    switch (l1 & 3) {
+        case 1: prdc_kernel<true, false><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, md); break;
+        case 3: prdc_kernel<true, true><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, md); break;
+        case 2: prdc_kernel<false, true><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, md); break;
+        default: prdc_kernel<false, false><<<grid, NTH, 0, st>>>(real, nr, fake, nf, dim, rad_real, rad_fake, below_real, any_fake, md); break;
+    }
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -111,6 +111,19 @@ int k_row_sumsq(const float* X, float* out, long rows, int N, hipStream_t st);
 // coef[r] = gp_weight*(2/B)*(nrm-1)/nrm ; losses[2] += mean((nrm-1)^2)
 int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_weight, hipStream_t st);
 
+// fused gradient-penalty chain (gpchain.hip; exact fp32 in both precision modes) -----------------------------------------
+// g1 = m1 * ((m2 * w3) W2) for the B interpolate rows (a1 / a2: post-activation head values); zeroes nrm2 [B], dg1pre [B,H]
+int k_gp_front(const float* a1, const float* a2, const float* w3, const float* W2, float* g1, float* dg1pre, float* nrm2, int B,
+               int H, float slope, hipStream_t st);
+// grad [B,G] = g1 [B,H] W1x, W1x[k,g] = W1[k*ldw + g]; nrm2[b] += sum_g grad[b,g]^2 in the epilogue
+int k_gp_grad(const float* g1, const float* W1, long ldw, float* grad, float* nrm2, int B, int H, int G, hipStream_t st);
+// coef[b] = gp_weight*(2/B)*(nrm-1)/nrm ; *loss += mean((nrm-1)^2) ; g1s = coef * g1 (g1s may be null)
+int k_gp_coef_scale(const float* nrm2, const float* g1, float* coef, float* g1s, float* loss, int B, int H, float gp_weight,
+                    hipStream_t st);
+// du = m1 * coef * dg1pre ; dW2 += (m2*w3)^T du ; dw3 += sum_b m2 * (du W2^T)   (atomic adds)
+int k_gp_tail(const float* dg1pre, const float* coef, const float* a1, const float* a2, const float* w3, const float* W2, float* dW2,
+              float* dw3, int B, int H, float slope, hipStream_t st);
+
 // fused self-attention (attention.hip): bf16 MFMA, no [S,S] tensor in HBM -----------------------------------
 bool flash_attn_supported(int S, int E, int nh);
 // qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S].

@@ -52,6 +52,12 @@ class Engine:
             self._alloc_workspace()
             self.losses = torch.zeros(L.N_LOSSES, dtype=torch.float32, device=self.device)
         self.dropout = float(dropout)
+        self._keep_ring = []
+        off, numel = C.c_int64(), C.c_int64()
+        self.mlp_range = {}
+        for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+            L.check(self.lib.gg_mlp_grad_range(self.h, r, C.byref(off), C.byref(numel)))
+            self.mlp_range[r] = (off.value, numel.value)
 
     # -- construction helpers ------------------------------------------------------------------
     def _read_layout(self, role):
@@ -109,10 +115,25 @@ class Engine:
         B, P, T = patches.shape[0], patches.shape[1], text.shape[1]
         if tuple(patch_pad.shape) != (B, P) or tuple(text_pad.shape) != (B, T):
             raise ValueError("padding mask shape mismatch")
-        pp = patch_pad.to(torch.uint8).contiguous() if patch_pad.dtype != torch.uint8 else patch_pad.contiguous()
-        tp = text_pad.to(torch.uint8).contiguous() if text_pad.dtype != torch.uint8 else text_pad.contiguous()
+        pp, tp = self._mask_bytes(patch_pad), self._mask_bytes(text_pad)
         keep = (patches, pp, text, tp)
+        # The engine's own streams (generator prefetch, side leaves) may still read these buffers after the C call returns;
+        # the caching allocator orders frees against the CURRENT stream only, so the last few argument sets stay referenced
+        # here until later calls (each of which joins the engine's streams) have been enqueued.
+        self._keep_ring.append(keep)
+        if len(self._keep_ring) > 16:
+            self._keep_ring.pop(0)
         return L.GGCond(patches.data_ptr(), pp.data_ptr(), text.data_ptr(), tp.data_ptr(), B, P, T), keep
+
+    def _mask_bytes(self, m: torch.Tensor) -> torch.Tensor:
+        """torch.bool masks are one byte per element: the kernels read the caller's tensor in place (no uint8 temporary)."""
+        if m.device != self.device:
+            m = m.to(self.device)
+        if not m.is_contiguous():
+            m = m.contiguous()
+        if m.dtype == torch.bool:
+            return m.view(torch.uint8)
+        return m if m.dtype == torch.uint8 else (m != 0).view(torch.uint8)
 
     def forward(self, role, v, patches, patch_pad, text, text_pad, train=False) -> torch.Tensor:
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
@@ -128,6 +149,47 @@ class Engine:
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         alpha = alpha.reshape(-1).contiguous()
         L.check(self.lib.gg_critic_backward(self.h, _ptr(x_real), _ptr(z), _ptr(alpha), C.byref(cond), _ptr(self.losses), _stream()))
+
+    def critic_backward_head(self, x_real, z, alpha, patches, patch_pad, text, text_pad):
+        """First phase of a critic iteration: returns with the MLP-head gradient slots (`mlp_range`) complete."""
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        alpha = alpha.reshape(-1).contiguous()
+        self._keep_ring.append((x_real, z, alpha))
+        L.check(self.lib.gg_critic_backward_head(self.h, _ptr(x_real), _ptr(z), _ptr(alpha), C.byref(cond), _ptr(self.losses), _stream()))
+
+    def critic_backward_cond(self, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_critic_backward_cond(self.h, C.byref(cond), _stream()))
+
+    def critic_cond_prefetch(self, patches, patch_pad, text, text_pad):
+        """The critic's conditioning pass of the next critic iteration on this minibatch, computed ahead."""
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_critic_cond_prefetch(self.h, C.byref(cond), _stream()))
+
+    def gradient_penalty(self, x_real, x_fake, alpha, patches, patch_pad, text, text_pad, train=True) -> torch.Tensor:
+        """0-d tensor mean((|grad_x^ D(x^)| - 1)^2) for x^ = alpha*real + (1-alpha)*fake (R:351-374); no gradients written."""
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        for t in (x_real, x_fake):
+            if t.dim() != 2 or t.shape[0] != cond.B or t.shape[1] != self.cfg.n_genes:
+                raise ValueError(f"real / fake must be [B,{self.cfg.n_genes}]")
+        x_real = x_real.to(self.device, torch.float32).contiguous()
+        x_fake = x_fake.to(self.device, torch.float32).contiguous()
+        alpha = alpha.to(self.device, torch.float32).reshape(-1).contiguous()
+        if alpha.numel() != cond.B:
+            raise ValueError("alpha must have one entry per sample")
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        L.check(self.lib.gg_gradient_penalty(self.h, _ptr(x_real), _ptr(x_fake), _ptr(alpha), C.byref(cond), int(train), _ptr(out), _stream()))
+        self._keep_ring.append((x_real, x_fake, alpha))
+        return out[0]
+
+    def generator_backward_head(self, z, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        self._keep_ring.append((z,))
+        L.check(self.lib.gg_generator_backward_head(self.h, _ptr(z), C.byref(cond), _ptr(self.losses), _stream()))
+
+    def generator_backward_cond(self, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_generator_backward_cond(self.h, C.byref(cond), _stream()))
 
     def critic_apply(self, grad_scale=1.0):
         L.check(self.lib.gg_critic_apply(self.h, C.c_float(grad_scale), _stream()))

@@ -1,6 +1,8 @@
 """Device-side evaluation metrics on the HIP nearest-record kernels (csrc/evalnn.hip): drop-ins for the reference's privacy
 metrics ``dcr`` / ``nndr`` (src/privacy_evaluator.py:9-66, P below; ``gg_eval_nn2``) and for ``compute_prdc``
-(src/distribution_distances.py:102-142, R below; ``gg_eval_knn`` + ``gg_eval_prdc_counts``).  The reference builds a [128, N, G] difference tensor per batch
+(src/distribution_distances.py:102-142, R below; ``gg_eval_knn`` + ``gg_eval_prdc_counts``), and for the improved
+precision / recall of ``ManifoldEstimator`` / ``knn_precision_recall_features`` / ``get_precision_recall``
+(src/unsupervised_metrics.py:141-303, U below; the same two kernels with Euclidean distances and inclusive radii).  The reference builds a [128, N, G] difference tensor per batch
 and sorts every row; the kernel streams the gene dimension through LDS and keeps the two smallest distances per generated
 sample.  Same arguments (numpy arrays or tensors), same return value (a Python float)."""
 import ctypes as C
@@ -95,3 +97,65 @@ def compute_prdc(real_features, fake_features, nearest_k, device="cuda:0"):
     density = below.double().mean().item() / float(nearest_k)
     coverage = (mind < rad_real).double().mean().item()
     return dict(precision=precision, recall=recall, density=density, coverage=coverage)
+
+
+def _prdc_counts(real, fake, rad_real, rad_fake, mode):
+    lib = L.load()
+    nr, nf = real.shape[0], fake.shape[0]
+    with torch.cuda.device(real.device):
+        below = torch.empty(nf, dtype=torch.int32, device=real.device)
+        anyf = torch.empty(nr, dtype=torch.int32, device=real.device)
+        mind = torch.empty(nr, dtype=torch.float32, device=real.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(lib.gg_eval_prdc_counts(C.c_void_p(real.data_ptr()), nr, C.c_void_p(fake.data_ptr()), nf, real.shape[1], mode,
+                                        C.c_void_p(rad_real.data_ptr()), C.c_void_p(rad_fake.data_ptr()), C.c_void_p(below.data_ptr()),
+                                        C.c_void_p(anyf.data_ptr()), C.c_void_p(mind.data_ptr()), stream))
+    return below, anyf, mind
+
+
+class ManifoldEstimator:
+    """U:141-244.  The manifold of `features` = union of hyperspheres around every sample whose radius reaches its
+    `nhood_sizes[0]`-th neighbour (the sample itself is the zeroth, U:188-189).  `D` holds the SQUARED radii like the
+    reference (its `batch_pairwise_distances` returns squared distances, U:114-138); `evaluate` says for every new vector
+    whether it falls inside (<=, U:223) at least one hypersphere.  One neighbourhood size per estimator (the reference's
+    callers pass a single one, U:297); row / column batch sizes are accepted and ignored (nothing is materialised)."""
+
+    def __init__(self, features, row_batch_size=25000, col_batch_size=50000, nhood_sizes=(3,), clamp_to_percentile=None, eps=1e-5,
+                 device="cuda:0"):
+        if len(nhood_sizes) != 1 or not 1 <= int(nhood_sizes[0]) <= 15:
+            raise ValueError("one neighbourhood size in [1, 15] per estimator")
+        if clamp_to_percentile is not None:
+            raise NotImplementedError("clamp_to_percentile is never used by the reference's callers")
+        self.nhood_sizes = list(nhood_sizes)
+        self.eps = eps
+        self._ref = _dev(features, device)
+        k = int(nhood_sizes[0])
+        self._radius = kth_smallest(self._ref, self._ref, k + 1, l1=False)[:, k].contiguous()      # Euclidean
+        self.D = (self._radius * self._radius).reshape(-1, 1).cpu().numpy()
+
+    def evaluate(self, eval_features):
+        """[n_eval, 1] int32: 1 where the vector lies inside the manifold."""
+        ev = _dev(eval_features, self._ref.device)
+        dummy = torch.zeros(ev.shape[0], device=ev.device)          # radii of the evaluated side are not needed here
+        below, _, _ = _prdc_counts(self._ref, ev, self._radius, dummy, 2)
+        return (below > 0).to(torch.int32).reshape(-1, 1).cpu().numpy()
+
+
+def knn_precision_recall_features(ref_features, eval_features, nhood_sizes=(3,), row_batch_size=10000, col_batch_size=50000,
+                                  num_gpus=1, device="cuda:0"):
+    """U:247-297: precision = share of `eval_features` inside the manifold of `ref_features`, recall = the converse.  Both
+    come out of ONE counting pass over the never-materialised [ref x eval] distance matrix."""
+    if len(nhood_sizes) != 1 or not 1 <= int(nhood_sizes[0]) <= 15:
+        raise ValueError("one neighbourhood size in [1, 15]")
+    k = int(nhood_sizes[0])
+    ref, ev = _dev(ref_features, device), _dev(eval_features, device)
+    rad_ref = kth_smallest(ref, ref, k + 1, l1=False)[:, k].contiguous()
+    rad_ev = kth_smallest(ev, ev, k + 1, l1=False)[:, k].contiguous()
+    below, anyf, _ = _prdc_counts(ref, ev, rad_ref, rad_ev, 2)
+    return {"precision": np.array([(below > 0).double().mean().item()]), "recall": np.array([(anyf > 0).double().mean().item()])}
+
+
+def get_precision_recall(real_data, fake_data, nb_nn=(10,), device="cuda:0"):
+    """U:300-323: (precision, recall) of `fake_data` against `real_data`."""
+    state = knn_precision_recall_features(real_data, fake_data, nhood_sizes=list(nb_nn), device=device)
+    return state["precision"][0], state["recall"][0]

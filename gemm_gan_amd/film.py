@@ -77,7 +77,18 @@ class WGAN_GP(_m.WGAN_GP):
         return text, torch.zeros(B, 1, dtype=torch.bool, device=self.device)
 
     def gradient_penalty(self, real_data, fake_data, text_embedding, patches, padding_mask):
-        raise NotImplementedError("the penalty is computed in closed form inside train_disc (no autograd graph on this path)")
+        """F:322-345: the penalty value (0-d tensor, no autograd graph; alpha drawn by the same torch.rand call)."""
+        text, tpad = self._text(text_embedding, real_data.shape[0])
+        return super().gradient_penalty(real_data, fake_data, patches, padding_mask, text, tpad)
+
+    # F:473-564 (balanced=False branch): batches are (text_embedding, gene_expression, patches, padding_mask, disease, site)
+    def _generate_from_batch(self, batch):
+        dev = self.device
+        return self.generate_samples(batch[1].to(dev), batch[0].to(dev), batch[2].to(dev), batch[3].to(dev))
+
+    @staticmethod
+    def _labels_of(batch):
+        return batch[4].detach().cpu().numpy(), batch[5].detach().cpu().numpy()
 
     def train_disc(self, real_data, z, text_embedding, patches, padding_mask):
         text, tpad = self._text(text_embedding, z.shape[0])
@@ -99,5 +110,5 @@ class WGAN_GP(_m.WGAN_GP):
             x_gen = self.gen(z, text_embedding, patches, padding_mask)
         return x_real, x_gen
 
-    def _fit_batch(self, data):
+    def _fit_batch(self, data, nxt=None):
         self.train(data[1], data[0], data[2], data[3])          # F:632-637: (text_embedding, gene_expression, patches, padding_mask)

@@ -218,6 +218,9 @@ class WGAN_GP:
         self.engine: Optional[Engine] = None
         self.gen = self.disc = None
         self.optimizer_disc = self.optimizer_gen = None
+        self._noise_gen = None
+        self.measure_comm = False
+        self._comm_events = []
 
     # ---- construction (R:334-349, R:320-331) -------------------------------------------------------
     def _build_nets(self):
@@ -272,16 +275,67 @@ class WGAN_GP:
             self.engine.set_lr(L.ROLE_CRITIC, self.optimizer_disc.param_groups[0]["lr"])
             self.engine.set_lr(L.ROLE_GENERATOR, self.optimizer_gen.param_groups[0]["lr"])
 
-    # ---- data-parallel plumbing ---------------------------------------------------------------------------
+    # ---- data-parallel plumbing ----------------------------------------------------------------
     def _world(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group)
         return 1
 
+    def _rank(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.process_group)
+        return 0
+
+    def _noise_generator(self):
+        """z / alpha stream of this rank.  One rank: the default torch generator, i.e. exactly the reference's draws
+        (R:473, R:354, R:476).  Data parallel: every rank owns a shard of the global minibatch and must draw ITS rows'
+        noise, so each rank gets its own generator seeded from (torch.initial_seed(), rank) - a global batch of N*B then
+        has N*B distinct latent vectors, as one GPU on that batch would."""
+        if self._world() == 1:
+            return None
+        if self._noise_gen is None:
+            g = torch.Generator(device=self.device)
+            g.manual_seed((torch.initial_seed() + 1000003 * (self._rank() + 1)) % (2 ** 63))
+            self._noise_gen = g
+        return self._noise_gen
+
     def _allreduce(self, role):
         import torch.distributed as dist
         dist.all_reduce(self.engine.flat[role]["g"], op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def _allreduce_bucket(self, role, which):
+        """Asynchronous SUM all-reduce of one of the two gradient buckets: 'mlp' = the MLP-head slots (complete after the
+        head phase of the backward), 'cond' = the conditioning-stack slots (complete at its end)."""
+        import torch.distributed as dist
+        off, numel = self.engine.mlp_range[role]
+        g = self.engine.flat[role]["g"]
+        t = g[off:off + numel] if which == "mlp" else g[:off]
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+
+    def _wait(self, *works):
+        """The compute stream waits for the collectives; with `measure_comm` the exposed wait is timed with an event pair."""
+        timed = self.measure_comm and self.device.type == "cuda"
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in works:
+            if w is not None:
+                w.wait()
+        if timed:
+            e1.record()
+            self._comm_events.append((e0, e1))
+
+    def comm_wait_ms(self, reset=True):
+        """Milliseconds the compute stream spent waiting for gradient all-reduces since the last reset (synchronises)."""
+        ms = 0.0
+        for e0, e1 in self._comm_events:
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        if reset:
+            self._comm_events = []
+        return ms
 
     def _prep(self, gene_expression, text_token, text_token_padding, patches, padding_mask):
         dev = self.device
@@ -293,16 +347,27 @@ class WGAN_GP:
         self._ensure_capacity(x.shape[0], pat.shape[1], text.shape[1])
         return x, text, tpad, pat, ppad
 
+    # ---- gradient penalty as a public call (R:351-374; note the argument order, which differs from train_disc) -----------
+    def gradient_penalty(self, real_data, fake_data, patches, padding_mask, text_token, text_token_padding):
+        """0-d tensor mean((||grad_x^ D(x^)||_2 - 1)^2), x^ = alpha*real + (1-alpha)*fake with alpha ~ U[0,1) drawn here
+        by the same torch.rand call as R:354.  The reference returns a tensor with an autograd graph; training on this
+        path goes through train_disc, whose double backward is hand-written, so the value carries no graph."""
+        x, text, tpad, pat, ppad = self._prep(real_data, text_token, text_token_padding, patches, padding_mask)
+        alpha = torch.rand(x.shape[0], 1, device=self.device)
+        return self.engine.gradient_penalty(x, fake_data, alpha, pat, ppad, text, tpad, train=self.disc.training)
+
     # ---- trainer (R:376-477) ------------------------------------------------------------------------------------
     def train_disc(self, real_data, z, text_token, text_token_padding, patches, padding_mask):
         x, text, tpad, pat, ppad = self._prep(real_data, text_token, text_token_padding, patches, padding_mask)
         self._sync_lr()
         alpha = torch.rand(x.shape[0], 1, device=self.device)             # R:354 (same draw, same place)
         eng = self.engine
-        eng.critic_backward(x, z.to(self.device, torch.float32).contiguous(), alpha, pat, ppad, text, tpad)
+        z = z.to(self.device, torch.float32).contiguous()
         w = self._world()
-        if w > 1:
-            self._allreduce(L.ROLE_CRITIC)
+        if w == 1:
+            eng.critic_backward(x, z, alpha, pat, ppad, text, tpad)
+        else:
+            self._critic_iteration_dp(x, z, alpha, pat, ppad, text, tpad)
         eng.critic_apply(1.0 / w)
         self._publish_critic_losses()
 
@@ -313,24 +378,58 @@ class WGAN_GP:
         self._ensure_capacity(z.shape[0], pat.shape[1], text.shape[1])
         self._sync_lr()
         eng = self.engine
-        eng.generator_backward(z.to(dev, torch.float32).contiguous(), pat, padding_mask.to(dev), text, text_token_padding.to(dev))
+        z = z.to(dev, torch.float32).contiguous()
+        ppad, tpad = padding_mask.to(dev), text_token_padding.to(dev)
         w = self._world()
-        if w > 1:
-            self._allreduce(L.ROLE_GENERATOR)
+        if w == 1:
+            eng.generator_backward(z, pat, ppad, text, tpad)
+        else:
+            self._generator_iteration_dp(z, pat, ppad, text, tpad)
         eng.generator_apply(1.0 / w)
         self._publish_gen_loss()
+
+    def _critic_iteration_dp(self, x, z, alpha, pat, ppad, text, tpad):
+        """Backward of one critic iteration with the all-reduce in two buckets: the MLP-head + gradient-penalty gradients
+        travel while the conditioning stack's backward runs (SURVEY 8e "Overlap")."""
+        eng = self.engine
+        eng.critic_backward_head(x, z, alpha, pat, ppad, text, tpad)
+        h1 = self._allreduce_bucket(L.ROLE_CRITIC, "mlp")
+        eng.critic_backward_cond(pat, ppad, text, tpad)
+        h2 = self._allreduce_bucket(L.ROLE_CRITIC, "cond")
+        self._wait(h1, h2)
+
+    def _generator_iteration_dp(self, z, pat, ppad, text, tpad, next_cond=None):
+        """Same for the generator; `next_cond` = (patches, pad, text, text_pad) of the NEXT train(): the critic's conditioning
+        forward of its first critic iteration does not depend on the generator and runs under the all-reduce."""
+        eng = self.engine
+        eng.generator_backward_head(z, pat, ppad, text, tpad)
+        h1 = self._allreduce_bucket(L.ROLE_GENERATOR, "mlp")
+        eng.generator_backward_cond(pat, ppad, text, tpad)
+        h2 = self._allreduce_bucket(L.ROLE_GENERATOR, "cond")
+        if next_cond is not None:
+            eng.critic_cond_prefetch(*next_cond)
+        self._wait(h1, h2)
 
     # ---- losses (R:421-423, R:458-460) -------------------------------------------------------------------------------
     # The reference publishes disc_loss / gen_loss (0-d tensors) and d_batch_loss / g_batch_loss (numpy) after every call,
     # with three .item() host syncs per critic iteration.  Here a call leaves a DEVICE snapshot of the engine's loss
     # slots (an async 24-byte copy on the same stream); the attributes are computed from it when read, so a loop that
     # does not look at the losses never stalls the host, and one that does (fit(), like the reference) syncs once.
+    def _global_mean(self, t):
+        """Data parallel: the batch means of the loss slots are per shard; equal shards => mean of means = global mean."""
+        w = self._world()
+        if w > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+            t /= w
+        return t
+
     def _publish_critic_losses(self):
-        self._crit_snap = self.engine.losses.clone()
+        self._crit_snap = self._global_mean(self.engine.losses.clone())
         self._crit_host = None
 
     def _publish_gen_loss(self):
-        self._gen_snap = self.engine.losses[L.LOSS_G].clone()
+        self._gen_snap = self._global_mean(self.engine.losses[L.LOSS_G:L.LOSS_G + 1].clone())[0]
         self._gen_host = None
 
     def _crit_values(self):
@@ -363,21 +462,29 @@ class WGAN_GP:
             self._gen_host = float(self._gen_snap)
         return np.array([self._gen_host])
 
-    def train(self, gene_expression, text_token, text_token_padding, patches, padding_mask):
+    def train(self, gene_expression, text_token, text_token_padding, patches, padding_mask, next_batch=None):
+        """One WGAN-GP step (R:463-477).  `next_batch` (extension, data parallel only): the (gene_expression, text_token,
+        text_token_padding, patches, padding_mask) of the following call, whose critic conditioning forward then runs
+        under this step's generator all-reduce; results are identical with or without it."""
         x, text, tpad, pat, ppad = self._prep(gene_expression, text_token, text_token_padding, patches, padding_mask)
         self._sync_lr()
         B, n = x.shape[0], self.n_critic
         dev = self.device
+        gen = self._noise_generator()
         # same torch RNG draws, in the same order, as the reference loop (z, alpha) x n_critic, then z (R:472-476)
         z_all = torch.empty(n + 1, B, self.latent_dims, device=dev)
         alpha_all = torch.empty(n, B, device=dev)
         for k in range(n):
-            z_all[k] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev)
-            alpha_all[k] = torch.rand(B, 1, device=dev).view(B)
-        z_all[n] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev)
-        self.train_with_noise(x, text, tpad, pat, ppad, z_all, alpha_all)
+            z_all[k] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev, generator=gen)
+            alpha_all[k] = torch.rand(B, 1, device=dev, generator=gen).view(B)
+        z_all[n] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev, generator=gen)
+        next_cond = None
+        if next_batch is not None and self._world() > 1:
+            _, ntext, ntpad, npat, nppad = self._prep(*next_batch)
+            next_cond = (npat, nppad, ntext, ntpad)
+        self.train_with_noise(x, text, tpad, pat, ppad, z_all, alpha_all, next_cond=next_cond)
 
-    def train_with_noise(self, x, text, tpad, pat, ppad, z_all, alpha_all, sync_losses=True):
+    def train_with_noise(self, x, text, tpad, pat, ppad, z_all, alpha_all, sync_losses=True, next_cond=None):
         """One train() with explicit z [n_critic+1,B,L] / alpha [n_critic,B] (parity and DP tests)."""
         eng = self.engine
         self._sync_lr()
@@ -386,14 +493,14 @@ class WGAN_GP:
         if w == 1:
             eng.train_step(x, pat, ppad, text, tpad, z_all, alpha_all)     # whole step enqueued by ONE C call
         else:
+            # One flat-buffer SUM all-reduce per optimiser step, issued as two buckets so that it overlaps the backward
+            # (SURVEY 8e); clip + step on the averaged gradient, identical on every rank.
             if n > 1:
                 eng.generator_prefetch(z_all[:n].contiguous(), pat, ppad, text, tpad)   # frozen generator: all n passes at once
             for k in range(n):
-                eng.critic_backward(x, z_all[k], alpha_all[k], pat, ppad, text, tpad)
-                self._allreduce(L.ROLE_CRITIC)
+                self._critic_iteration_dp(x, z_all[k], alpha_all[k], pat, ppad, text, tpad)
                 eng.critic_apply(1.0 / w)
-            eng.generator_backward(z_all[n], pat, ppad, text, tpad)
-            self._allreduce(L.ROLE_GENERATOR)
+            self._generator_iteration_dp(z_all[n], pat, ppad, text, tpad, next_cond)
             eng.generator_apply(1.0 / w)
         if sync_losses:
             self._publish_critic_losses()
@@ -408,15 +515,69 @@ class WGAN_GP:
             x_gen = self.gen(z, patches, padding_mask, text_embedding, text_padding)
         return x_real, x_gen
 
-    def _fit_batch(self, data):
-        self.train(data[2], data[0], data[1], data[3], data[4])             # R:667-673
+    def _fit_batch(self, data, nxt=None):
+        nb = None if nxt is None else (nxt[2], nxt[0], nxt[1], nxt[3], nxt[4])
+        self.train(data[2], data[0], data[1], data[3], data[4], next_batch=nb)             # R:667-673
+
+    # ---- sample dumps consumed by the reference's evaluators (R:561-599 balanced=False branch, R:793-806) -------------
+    def generate_samples_all(self, data_loader, num_repeats=1, balanced=False, balanced_max_oversample=5):
+        """(all_real_x, all_gen_x, disease_real, disease_gen, primary_site_real, primary_site_gen) as numpy arrays, one
+        generator pass per minibatch and repeat (R:561-599).  `balanced=True` raises NameError in the reference (R:531:
+        `text_padding` used before assignment) and is not offered."""
+        if balanced:
+            raise NotImplementedError("generate_samples_all(balanced=True) is broken upstream (R:531); use balanced=False")
+        all_real, all_gen, dis_real, dis_gen, site_real, site_gen = [], [], [], [], [], []
+        for i in range(num_repeats):
+            for batch in data_loader:
+                x_real, x_gen = self._generate_from_batch(batch)
+                dis, site = self._labels_of(batch)
+                all_gen.append(x_gen.detach().cpu().numpy())
+                dis_gen.append(dis)
+                site_gen.append(site)
+                if i == 0:
+                    all_real.append(x_real.detach().cpu().numpy())
+                    dis_real.append(dis)
+                    site_real.append(site)
+        return (np.vstack(all_real), np.vstack(all_gen), np.concatenate(dis_real, axis=0), np.concatenate(dis_gen, axis=0),
+                np.concatenate(site_real, axis=0), np.concatenate(site_gen, axis=0))
+
+    def _generate_from_batch(self, batch):
+        dev = self.device
+        return self.generate_samples(batch[2].to(dev), batch[0].to(dev), batch[1].to(dev), batch[3].to(dev), batch[4].to(dev))
+
+    @staticmethod
+    def _labels_of(batch):
+        return batch[5].detach().cpu().numpy(), batch[6].detach().cpu().numpy()
+
+    def dump_generated(self, train_data, test_data, epoch, n_runs=2):
+        """The twelve .npy files per run that the reference writes at the last epoch (R:786-806) and its evaluation scripts
+        read back: <results_dire>/test_<run>_epoch_<epoch+1>/{data,test}_{real,gen}.npy, {train,test}_labels_{real,gen}.npy,
+        {train,test}_primary_site_{real,gen}.npy."""
+        out = []
+        for run in range(n_runs):
+            tr = self.generate_samples_all(train_data)
+            te = self.generate_samples_all(test_data)
+            d = os.path.join(self.result_dire, f"test_{run}_epoch_{epoch + 1}")
+            os.makedirs(d, exist_ok=True)
+            files = {"data_real": tr[0], "data_gen": tr[1], "test_real": te[0], "test_gen": te[1],
+                     "train_labels_real": tr[2], "train_labels_gen": tr[3], "test_labels_real": te[2], "test_labels_gen": te[3],
+                     "train_primary_site_real": tr[4], "train_primary_site_gen": tr[5],
+                     "test_primary_site_real": te[4], "test_primary_site_gen": te[5]}
+            for name, arr in files.items():
+                with open(os.path.join(d, name + ".npy"), "wb") as f:
+                    np.save(f, arr)
+            out.append(d)
+        return out
 
     # ---- epoch loop (R:619-711): training, LR halving, loss bookkeeping, checkpoints ----------------------------
     def fit(self, train_data, val_data=None, test_data=None, epochs=1, val=False):
-        """Training part of the reference fit(): evaluation/plots (R:712-894) are out of scope."""
+        """Training part of the reference fit(): LR schedule, loss bookkeeping, checkpoints and - with `val` and a test
+        loader - the generated-sample dumps of the last epoch (R:786-806).  Metrics / plots (R:712-785, R:807-894) are the
+        sklearn / matplotlib side of the reference and stay out of scope."""
         self.build_WGAN_GP()
         if self.isTrain:
             self.init_train()
+        lookahead = self._world() > 1
         for epoch in range(epochs):
             if epoch % 100 == 0 and epoch != 0:                                  # R:649-657
                 for opt in (self.optimizer_disc, self.optimizer_gen):
@@ -424,8 +585,12 @@ class WGAN_GP:
                         group["lr"] = group["lr"] * 0.50
             self.epoch = epoch
             d_loss_all, d_batch_loss, g_batch_loss, nb = 0.0, None, None, 0
-            for i, data in enumerate(train_data):
-                self._fit_batch(data)
+            it = iter(train_data)
+            data = next(it, None)
+            i = 0
+            while data is not None:
+                nxt = next(it, None)
+                self._fit_batch(data, nxt if lookahead else None)
                 d_loss_all += self.disc_loss.item()
                 d_batch_loss = self.d_batch_loss if d_batch_loss is None else d_batch_loss + self.d_batch_loss
                 g_batch_loss = self.g_batch_loss if g_batch_loss is None else g_batch_loss + self.g_batch_loss
@@ -433,6 +598,8 @@ class WGAN_GP:
                 if (i + 1) % self.freq_print == 0:
                     print("[Epoch %d/%d] [Batch %d/%d] [D loss : %f] [G loss : %f]"
                           % (epoch + 1, epochs, i + 1, len(train_data), self.disc_loss.item(), self.gen_loss.item()))
+                data = nxt
+                i += 1
             d_batch_loss = d_batch_loss / max(nb, 1)
             self.loss_dict["d loss"].append(d_batch_loss[0])
             self.loss_dict["d real loss"].append(d_batch_loss[1])
@@ -442,6 +609,8 @@ class WGAN_GP:
             if self.result_dire and (epoch + 1) % self.freq_compute_test == 0:       # R:710-711
                 torch.save(self.gen.state_dict(), os.path.join(self.result_dire, f"generator_epoch_{epoch + 1}.pt"))
                 torch.save(self.disc.state_dict(), os.path.join(self.result_dire, f"discriminator_epoch_{epoch + 1}.pt"))
+                if val and test_data is not None and (epoch + 1) == epochs:              # R:739, R:786-806
+                    self.dump_generated(train_data, test_data, epoch)
         if self.result_dire:                                                           # R:743-744
             torch.save(self.gen.state_dict(), os.path.join(self.result_dire, "generator_last_epoch.pt"))
             torch.save(self.disc.state_dict(), os.path.join(self.result_dire, "discriminator_last_epoch.pt"))

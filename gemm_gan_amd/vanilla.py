@@ -11,6 +11,7 @@ the engine returns before touching them (its conditioning vector is identically 
 weights live in the engine with ``embedding_dims`` extra zero columns; the modules here expose the reference's ``[H, V]``
 block (a strided view), so ``state_dict`` keys AND shapes are the reference's.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -127,7 +128,18 @@ class WGAN_GP_nocond(_m.WGAN_GP):
         self.build_WGAN_GP()
 
     def gradient_penalty(self, real_data, fake_data):
-        raise NotImplementedError("the penalty is computed in closed form inside train_disc (no autograd graph on this path)")
+        """V:304-327: the penalty value (0-d tensor, no autograd graph; alpha drawn by the same torch.rand call)."""
+        text, tpad, pat, ppad = self._cond(real_data.shape[0])
+        return super().gradient_penalty(real_data, fake_data, pat, ppad, text, tpad)
+
+    def generate_samples_all(self, data):
+        """V:433-459: (all_real_x, all_gen_x) over a loader whose items carry the expression matrix first."""
+        all_real, all_gen = [], []
+        for item in data:
+            x_real, x_gen = self.generate_samples((item[0] if isinstance(item, (tuple, list)) else item).to(self.device))
+            all_real.append(x_real.cpu().detach().numpy())
+            all_gen.append(x_gen.cpu().detach().numpy())
+        return np.vstack(all_real), np.vstack(all_gen)
 
     def _cond(self, B):
         self._ensure_capacity(B, 1, 1)
@@ -156,5 +168,5 @@ class WGAN_GP_nocond(_m.WGAN_GP):
             x_gen = self.gen(z)
         return x_real, x_gen
 
-    def _fit_batch(self, data):
+    def _fit_batch(self, data, nxt=None):
         self.train(data[0] if isinstance(data, (tuple, list)) else data)     # V:576-579: data[0] is the expression matrix

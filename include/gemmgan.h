@@ -130,9 +130,35 @@ int gg_critic_backward(gg_engine* e, const float* x_real, const float* z, const 
                        const gg_cond* c, float* losses, void* stream);
 int gg_critic_apply(gg_engine* e, float grad_scale, void* stream);
 
+/* The same iteration in two phases, for data-parallel hosts that overlap the gradient all-reduce with the backward pass:
+ * ..._head runs everything up to and including the MLP-head / gradient-penalty gradients (R:391-409 and the head part of
+ * loss.backward(), R:412) and returns with the slots gg_mlp_grad_range() names complete on the caller's stream;
+ * ..._cond runs the conditioning stack's backward (the rest of R:412).  head + cond == gg_critic_backward. */
+int gg_critic_backward_head(gg_engine* e, const float* x_real, const float* z, const float* alpha,
+                            const gg_cond* c, float* losses, void* stream);
+int gg_critic_backward_cond(gg_engine* e, const gg_cond* c, void* stream);
+/* [offset, offset + numel) of the flat gradient buffer: the MLP-head parameters (`<mlp>.0.0`, `<mlp>.1.0`, final_layer),
+ * the last entries of the state_dict order; [0, offset) are the conditioning-stack parameters */
+int gg_mlp_grad_range(const gg_engine* e, int role, int64_t* offset, int64_t* numel);
+/* The critic's conditioning pass (R:403,404,360: its three dropout draws) of the NEXT gg_critic_backward[_head] call on the
+ * same minibatch shape, computed ahead: it depends on the critic's weights and the conditioning inputs only, so a
+ * data-parallel host runs it under the generator's gradient all-reduce.  Discarded by anything that changes the critic's
+ * weights or reuses its activation arena (gg_critic_apply, gg_forward(critic), gg_generator_backward). */
+int gg_critic_cond_prefetch(gg_engine* e, const gg_cond* c, void* stream);
+
+/* ---- WGAN_GP.gradient_penalty (R:351-374) as a call of its own ---------------------------------------------------
+ * *gp_out (device float) = mean_b (|grad_x^ D(x^_b)|_2 - 1)^2 for x^ = alpha*real + (1-alpha)*fake, alpha [B] supplied by the
+ * caller (R:354 draws it with torch.rand).  train != 0: dropout as in train() mode.  No gradient buffer is written; the
+ * gradient itself ([B,G]) is left in the debug buffer "gp_grad". */
+int gg_gradient_penalty(gg_engine* e, const float* x_real, const float* x_fake, const float* alpha, const gg_cond* c,
+                        int train, float* gp_out, void* stream);
+
 /* ---- one generator update: WGAN_GP.train_gen (R:425-461) ------------------------------------------ */
 int gg_generator_backward(gg_engine* e, const float* z, const gg_cond* c, float* losses, void* stream);
 int gg_generator_apply(gg_engine* e, float grad_scale, void* stream);
+/* two-phase form (see gg_critic_backward_head): head = R:441-455 down to the generator's MLP-head gradients */
+int gg_generator_backward_head(gg_engine* e, const float* z, const gg_cond* c, float* losses, void* stream);
+int gg_generator_backward_cond(gg_engine* e, const gg_cond* c, void* stream);
 
 /* ---- optional: the frozen generator's outputs for the next n critic iterations, computed ahead -------------
  * WGAN_GP.train (R:463-477) calls train_disc n_critic times on ONE conditioning batch with the generator frozen, so
@@ -205,7 +231,8 @@ int64_t gg_launch_count(const gg_engine* e);
 /* PRDC (src/distribution_distances.py:87-142; the reference uses L1 distances there, :64): the k smallest distances of every
  * query row to `refs`, ascending, out [nq, gg_eval_knn_width(k)] (1 <= k <= 16; l1 != 0: sum |q - r|, else Euclidean); and
  * the counting pass over the never-materialised [real x fake] distance matrix: below_real[j] = #{i: d_ij < rad_real[i]},
- * any_fake[i] = any_j d_ij < rad_fake[j], min_d[i] = min_j d_ij. */
+ * any_fake[i] = any_j d_ij < rad_fake[j], min_d[i] = min_j d_ij.  gg_eval_prdc_counts: l1 bit 0 = L1 distances, bit 1 = inclusive
+ * comparisons (d <= radius: ManifoldEstimator.evaluate, src/unsupervised_metrics.py:223, with Euclidean distances). */
 long gg_eval_knn_scratch(long nq, long nr, int k);
 int gg_eval_knn_width(int k);
 int gg_eval_knn(const float* queries, long nq, const float* refs, long nr, int dim, int k, int l1, float* out, float* scratch,

@@ -301,7 +301,7 @@ def make_fixture(ref, name, dims, seed):
             out[f"critic1/grad/{n}"] = gpre.numpy()
         else:
             out[f"critic1/grad_none/{n}"] = np.zeros(0, dtype=np.float32)
-    sd_to_np("critic1/post_disc", w1.disc.state_dict(), out, stride=3)
+    sd_to_np("critic1/post_disc", w1.disc.state_dict(), out)
 
     # ---- one generator iteration (train_gen :425-461) from the initial state
     w2 = build(ref, dims, "rms_prop", init)
@@ -318,7 +318,7 @@ def make_fixture(ref, name, dims, seed):
     for (n, _p), gpre in zip(w2.gen.named_parameters(), pre):
         if gpre is not None:
             out[f"gen1/grad/{n}"] = gpre.numpy()
-    sd_to_np("gen1/post_gen", w2.gen.state_dict(), out, stride=3)
+    sd_to_np("gen1/post_gen", w2.gen.state_dict(), out)
 
     # ---- full train() (:463-477) for the three optimisers
     # conditional_gan_img_transformer.py:277-286 knows rms_prop and adam only
@@ -335,9 +335,8 @@ def make_fixture(ref, name, dims, seed):
         out[f"step_{opt}/disc_loss"] = np.float64(float(w.disc_loss))
         out[f"step_{opt}/gen_loss"] = np.float64(float(w.gen_loss))
         out[f"step_{opt}/grad_norms"] = np.array([c[1] for c in rec.clips], dtype=np.float64)
-        stride = 1 if opt == "rms_prop" else 5
-        sd_to_np(f"step_{opt}/post_gen", w.gen.state_dict(), out, stride=stride)
-        sd_to_np(f"step_{opt}/post_disc", w.disc.state_dict(), out, stride=stride)
+        sd_to_np(f"step_{opt}/post_gen", w.gen.state_dict(), out)          # every element (no subsampling)
+        sd_to_np(f"step_{opt}/post_disc", w.disc.state_dict(), out)
 
     os.makedirs(OUT_DIR, exist_ok=True)
     path = os.path.join(OUT_DIR, f"{name}.npz")

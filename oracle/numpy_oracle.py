@@ -388,18 +388,24 @@ class Optim:
 
 
 def train_step(pg, pd, opt_g, opt_d, x_real, cond, z_list, alpha_list, slope=0.0, gp_weight=10.0,
-               clip_d=10.0, clip_g=2.0, nh=4, n_layers=2):
-    """R:463-477.  Mutates pg / pd in place; returns last critic losses and the generator loss."""
+               clip_d=10.0, clip_g=2.0, nh=4, n_layers=2, grad_hook=None):
+    """R:463-477.  Mutates pg / pd in place; returns last critic losses and the generator loss.
+    grad_hook(grads) -> grads (optional) sees every gradient dict before clipping: conditioning experiments (how far
+    rounding-level gradient noise moves a multi-step result) run through it."""
     n_critic = len(alpha_list)
     losses = None
     for k in range(n_critic):
         losses, g, _, _ = critic_iteration_grads(pg, pd, x_real, z_list[k], alpha_list[k], cond,
                                                  slope, gp_weight, nh, n_layers)
+        if grad_hook is not None:
+            g = grad_hook(g)
         if clip_d is not None:
             _, coef = clip_coef(g, clip_d)
             g = {n: v * coef for n, v in g.items()}
         opt_d.step(pd, g)
     g_loss, g, _ = generator_iteration_grads(pg, pd, z_list[n_critic], cond, slope, nh, n_layers)
+    if grad_hook is not None:
+        g = grad_hook(g)
     if clip_g is not None:
         _, coef = clip_coef(g, clip_g)
         g = {n: v * coef for n, v in g.items()}

@@ -1,0 +1,189 @@
+"""Numbers on the bf16 throughput mode (the mode bench.py's headline runs in) against the fp32 references: per-stage and
+per-gradient relative errors with explicit bounds - on the golden fixtures of the REAL reference (tiny widths: the generic
+bf16 GEMM route) and on the production-width cases of the fused kernels (`hot_tiles_E256`, `cls_tail_S257`: token-on-lane
+Linear, flash attention, weight-gradient kernel) - and a 25-step training trajectory at the headline shape in both modes.
+
+bf16 keeps 8 significant bits: a product of two rounded operands carries ~2^-8 relative error per term, a length-K dot
+product of such terms ~2^-8/sqrt(K)..2^-8 of its magnitude.  Metric: relative L2 error ||a - b||_2 / ||b||_2 per tensor (the
+per-element error of a near-zero entry says nothing in 8-bit arithmetic); bounds: activations 1e-2, losses 1e-2,
+gradient tensors 5e-2 (they pass through ~10 rounded products and the ReLU gates of a small batch).  The f32 mode is
+gated elementwise at 1e-3 elsewhere (tests/test_engine_golden_gpu.py, tests/test_engine_oracle_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gemm_gan_amd import _lib as L
+from golden_util import XATTN_FIXTURES, Golden
+from gpu_util import dev, diag, engine_from_cfg
+from test_engine_oracle_gpu import CASES, setup
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL, LOSS_TOL, GRAD_TOL = 1e-2, 1e-2, 5e-2
+
+
+def l2(a, b):
+    a = a.detach().double().cpu().numpy().reshape(-1) if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64).reshape(-1)
+    b = b.detach().double().cpu().numpy().reshape(-1) if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64).reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if not np.isfinite(a).all():
+        return float("inf")
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+class Gate:
+    def __init__(self, tag):
+        self.tag, self.bad, self.worst = tag, [], {}
+        diag(f"== {tag}")
+
+    def check(self, kind, name, got, want, tol):
+        e = l2(got, want)
+        self.worst[kind] = max(self.worst.get(kind, 0.0), e)
+        flag = "" if e <= tol else "   <-- FAIL"
+        diag(f"   {kind:5s} {name:60s} rel-L2 {e:.3e} (bound {tol:g}){flag}")
+        if flag:
+            self.bad.append((name, e))
+
+    def done(self):
+        diag("   worst: " + ", ".join(f"{k} {v:.3e}" for k, v in self.worst.items()))
+        assert not self.bad, f"{self.tag}: " + ", ".join(f"{n} ({e:.2e})" for n, e in self.bad[:12])
+
+
+def significant(ref):
+    """Gradient tensors that are identically (or numerically) zero in the reference carry no direction to compare."""
+    return ref is not None and float(ref.abs().max()) > 1e-10
+
+
+@pytest.mark.parametrize("name", XATTN_FIXTURES)
+def test_bf16_vs_golden_fixtures(name):
+    g = Golden(name)
+    d = g.dims
+    cfg = g.cfg()
+    eng = engine_from_cfg(cfg, d["B"], d["P"], d["T"], dropout=0.0)
+    eng.set_precision("bf16")
+    eng.load_state(L.ROLE_GENERATOR, g.state("init_gen"))
+    eng.load_state(L.ROLE_CRITIC, g.state("init_disc"))
+    x, text, text_pad, patches, patch_pad = dev(*g.inputs())
+    B, S, E = d["B"], d["P"] + 1, d["E"]
+    gt = Gate(f"bf16 vs golden {name}")
+    out = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=True)
+    ref = g.group("disc_fwd")
+    gt.check("act", "text encoder", eng.debug_buffer("D.tok").view(B, d["T"], E), ref["text_enc"], ACT_TOL)
+    gt.check("act", "patch encoder (FiLM fused)", eng.debug_buffer("D.x0").view(B, S, E)[:, 1:], ref["patch_emb"], ACT_TOL)
+    gt.check("act", "encoder layer 0", eng.debug_buffer("D.L0.x2").view(B, S, E), ref["enc_layer0"], ACT_TOL)
+    gt.check("act", "encoder layer 1", eng.debug_buffer("D.L1.x2").view(B, S, E), ref["enc_layer1"], ACT_TOL)
+    gt.check("act", "T2I attention", eng.debug_buffer("D.t2i_out").view(B, E), ref["t2i"], ACT_TOL)
+    gt.check("act", "I2T attention", eng.debug_buffer("D.i2t_out").view(B, E), ref["i2t"], ACT_TOL)
+    gt.check("act", "critic score", out, ref["out"], ACT_TOL)
+    xg = eng.forward(L.ROLE_GENERATOR, g.t("gen_fwd/z").cuda(), patches, patch_pad, text, text_pad, train=True)
+    gt.check("act", "generated genes", xg, g.z["gen_fwd/out"], ACT_TOL)
+    eng.critic_backward(x, g.t("critic1/z").cuda(), g.t("critic1/alpha").cuda(), patches, patch_pad, text, text_pad)
+    l = eng.losses.tolist()
+    los = g.z["critic1/losses"]
+    gt.check("loss", "d_real, d_fake", np.array([l[0], l[1]]), los[2:4], LOSS_TOL)
+    gt.check("loss", "gradient penalty", np.array([l[2]]), np.array([(los[0] - los[1]) / 10.0]), 2 * LOSS_TOL)
+    gt.check("grad", "grad_x_hat", eng.debug_buffer("gp_grad").view(B, d["G"]), g.z["critic1/grad_x_hat"], GRAD_TOL)
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    for n, r in g.group("critic1/grad").items():
+        if significant(torch.from_numpy(r)) and not n.endswith("in_proj_bias"):
+            gt.check("grad", "dD " + n, grads[n], r, GRAD_TOL)
+    eng.generator_backward(g.t("gen1/z").cuda(), patches, patch_pad, text, text_pad)
+    gt.check("loss", "g_loss", np.array([eng.losses.tolist()[3]]), np.array([float(g.z["gen1/loss"])]), LOSS_TOL)
+    grads = eng.state(L.ROLE_GENERATOR, "g")
+    for n, r in g.group("gen1/grad").items():
+        if significant(torch.from_numpy(r)) and not n.endswith("in_proj_bias"):
+            gt.check("grad", "dG " + n, grads[n], r, GRAD_TOL)
+    gt.done()
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+def test_bf16_fused_kernels_vs_fp32_oracle(case):
+    """Production width (E = 256, dh = 64): token-on-lane Linear, flash attention, projection-free T2I attention, the
+    weight-gradient kernel - stage activations against oracle #1's taps, then one critic and one generator iteration."""
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    eng.set_precision("bf16")
+    B, P, T = x.shape[0], patches.shape[1], text.shape[1]
+    S, E = P + 1, cfg.embedding_dims
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    gt = Gate(f"bf16 fused kernels vs fp32 oracle {case}")
+    taps = {}
+    with torch.no_grad():
+        tr.disc.train()
+        ref_out = tr.disc(x, *cond, taps=taps)
+    out = eng.forward(L.ROLE_CRITIC, xg, pg, ppg, tg, tpg, train=True)
+    gt.check("act", "text encoder", eng.debug_buffer("D.tok").view(B, T, E), taps["text_enc"], ACT_TOL)
+    gt.check("act", "patch encoder + CLS", eng.debug_buffer("D.x0").view(B, S, E), taps["seq0"], ACT_TOL)
+    gt.check("act", "encoder output", eng.debug_buffer("D.L1.x2").view(B, S, E), taps["enc"], ACT_TOL)
+    gt.check("act", "T2I attention", eng.debug_buffer("D.t2i_out").view(B, E), taps["t2i"], ACT_TOL)
+    gt.check("act", "I2T attention", eng.debug_buffer("D.i2t_out").view(B, E), taps["i2t"], ACT_TOL)
+    gt.check("act", "conditioning vector", eng.debug_buffer("D.c").view(B, E), taps["cond"], ACT_TOL)
+    gt.check("act", "critic score", out, ref_out, ACT_TOL)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    l = eng.losses.tolist()
+    gt.check("act", "generated genes", eng.debug_buffer("X2").view(2 * B, -1)[:B], r["x_fake"], ACT_TOL)
+    gt.check("loss", "d_real, d_fake", np.array(l[:2]), np.array([r["d_real"].item(), r["d_fake"].item()]), LOSS_TOL)
+    gt.check("loss", "gradient penalty", np.array([l[2]]), np.array([r["gp"].item()]), 2 * LOSS_TOL)
+    gt.check("grad", "grad_x_hat", eng.debug_buffer("gp_grad").view(B, -1), r["grad_x_hat"].detach(), GRAD_TOL)
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    for n, ref in r["grads"].items():
+        if significant(ref) and not n.endswith("in_proj_bias"):
+            gt.check("grad", "dD " + n, grads[n], ref, GRAD_TOL)
+    rg = tr.generator_iteration(z, cond, apply=False)
+    eng.generator_backward(zg, pg, ppg, tg, tpg)
+    gt.check("loss", "g_loss", np.array([eng.losses.tolist()[3]]), np.array([rg["g_loss"].item()]), LOSS_TOL)
+    grads = eng.state(L.ROLE_GENERATOR, "g")
+    for n, ref in rg["grads"].items():
+        if significant(ref) and not n.endswith("in_proj_bias"):
+            gt.check("grad", "dG " + n, grads[n], ref, GRAD_TOL)
+    gt.done()
+
+
+@pytest.mark.timeout(900)
+def test_training_trajectories_bf16_vs_f32_at_the_headline_shape():
+    """25 train() steps of cfg3 (B = 256, 5 000 genes, 256 x 1024 patch tokens, 1 x 512 text token, dropout 0.1) from the
+    same seeds in both precision modes: the bf16 run must stay inside a band around the exact-fp32 run (GAN training is
+    chaotic in the long run; 25 steps = 150 optimiser steps is where rounding has not yet decorrelated the runs)."""
+    import gemm_gan_amd as gga
+    device = torch.device("cuda:0")
+    G, B, P, T = 5000, 256, 256, 1
+
+    def run(prec, steps=25):
+        torch.manual_seed(42)
+        w = gga.WGAN_GP(G, 256, 256, [256, 256, G], [256, 256, 1], text_embedding_dims=512, patches_embedding_dims=1024,
+                        optimizer="rms_prop", n_critic=5, dropout=0.1, seed=1, device=device, results_dire="", precision=prec)
+        w.build_WGAN_GP()
+        w.init_train()
+        w.reserve(B, P, T)
+        g = torch.Generator(device=device).manual_seed(7)
+        x = torch.randn(B, G, device=device, generator=g)
+        patches = torch.randn(B, P, 1024, device=device, generator=g)
+        text = torch.randn(B, T, 512, device=device, generator=g)
+        pp = torch.zeros(B, P, dtype=torch.bool, device=device)
+        tp = torch.zeros(B, T, dtype=torch.bool, device=device)
+        torch.manual_seed(123)
+        out = []
+        for s in range(steps):
+            w.train(x, text, tp, patches, pp)
+            out.append((float(w.d_batch_loss[0]), float(w.g_batch_loss[0]), float(w.gp_value)))
+        del w
+        torch.cuda.empty_cache()
+        return np.array(out)
+
+    a, b = run("bf16"), run("f32")
+    diag("== trajectory bf16 vs f32 (cfg3, 25 steps): step, d_loss, g_loss, gp")
+    for s in (0, 4, 9, 14, 19, 24):
+        diag(f"   step {s:2d}  bf16 {a[s, 0]:10.3f} {a[s, 1]:9.3f} {a[s, 2]:8.4f}   f32 {b[s, 0]:10.3f} {b[s, 1]:9.3f} {b[s, 2]:8.4f}")
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    scale = np.abs(b).max(axis=0)                               # per-quantity scale of the fp32 trajectory
+    dev_ = np.abs(a - b) / scale
+    diag(f"   largest deviation / trajectory scale: d {dev_[:, 0].max():.3f}, g {dev_[:, 1].max():.3f}, gp {dev_[:, 2].max():.3f}")
+    assert dev_[:5].max() <= 0.02, dev_[:5].max()               # the first steps agree to bf16 rounding
+    assert dev_[:, 0].max() <= 0.10 and dev_[:, 2].max() <= 0.10, dev_.max(axis=0)       # critic loss, penalty: within 10 %
+    assert dev_[:, 1].max() <= 0.25, dev_[:, 1].max()           # generator loss: the most sensitive (-mean D(G(z)))
+    # same qualitative course: the critic loss falls by the same amount (+-15 %)
+    assert abs((a[-1, 0] - a[0, 0]) - (b[-1, 0] - b[0, 0])) <= 0.15 * abs(b[-1, 0] - b[0, 0])

@@ -1,10 +1,84 @@
-"""gemm_gan_amd/data.py against the reference loader's per-item semantics (src/multi_patch_multi_token_gan_dataloader.py:11-55,
-restated here: the reference tree is not read): on-disk formats, float64 -> float32 patches, inverted attention mask,
-subsample without replacement / zero padding with mask, tuple order, epoch permutations."""
+"""gemm_gan_amd/data.py against the reference loader (src/multi_patch_multi_token_gan_dataloader.py): per-item semantics
+pinned by items recorded from the REAL `MultiPatchMultiTokenGANDataset` (tests/golden/aux_loader_items.npz, written by
+oracle/make_golden_aux.py), the front half (`dataloader_multi_patch_conditional_gan`: gene filter, split, z-score, label
+encodings) by tests/golden/aux_loader_split.npz; plus on-disk formats, subsampling statistics, epoch permutations."""
+import os
+import pickle
+from pathlib import Path
+
 import numpy as np
 import torch
 
-from gemm_gan_amd.data import DeviceCaseCache
+from gemm_gan_amd.data import DeviceCaseCache, dataloader_multi_patch_conditional_gan
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_items_equal_the_recorded_reference_items(tmp_path):
+    """Every 7-tuple the reference Dataset returned for cases with fewer / exactly / more rows than num_patches."""
+    z = np.load(os.path.join(GOLDEN, "aux_loader_items.npz"))
+    counts, P = z["counts"], int(z["num_patches"])
+    pdir, tdir = tmp_path / "p", tmp_path / "t"
+    pdir.mkdir(); tdir.mkdir()
+    ids = []
+    for i in range(len(counts)):
+        cid = f"case{i}"
+        np.save(pdir / f"{cid}.npy", z[f"in/patches{i}"]); np.save(tdir / f"{cid}.npy", z[f"in/tokens{i}"])
+        np.save(tdir / f"{cid}_attention_mask.npy", z[f"in/mask{i}"])
+        ids.append(cid)
+    cache = DeviceCaseCache(ids, tdir, pdir, z["in/genes"], z["in/disease"], z["in/site"], num_patches=P, device="cpu")
+    tok, tpad, x, patches, pad, dis, site = cache.batch(list(range(len(counts))), torch.Generator().manual_seed(0))
+    for i, n in enumerate(counts):
+        assert np.array_equal(tok[i].numpy(), z[f"item{i}/tokens"]) and np.array_equal(tpad[i].numpy(), z[f"item{i}/token_pad"])
+        assert np.array_equal(x[i].numpy(), z[f"item{i}/genes"])
+        assert int(dis[i]) == int(z[f"item{i}/disease"]) and int(site[i]) == int(z[f"item{i}/site"])
+        assert np.array_equal(pad[i].numpy(), z[f"item{i}/patch_pad"])            # all False, also for the zero-padded cases
+        want = z[f"item{i}/patches"]
+        assert patches[i].dtype == torch.float32 and want.dtype == np.float32
+        if n <= P:
+            assert np.array_equal(patches[i].numpy(), want)                       # rows in file order, then zero rows
+        else:       # a random subset: same row set semantics (P distinct rows of the case), order and choice are the RNG's
+            src = z[f"in/patches{i}"].astype(np.float32)
+            for rows in (patches[i].numpy(), want):
+                hits = [np.flatnonzero((src == r).all(axis=1)) for r in rows]
+                assert all(len(h) == 1 for h in hits) and len({int(h[0]) for h in hits}) == P
+    # the documented opt-in: padded slots masked
+    fixed = DeviceCaseCache(ids, tdir, pdir, z["in/genes"], num_patches=P, device="cpu", mask_padding=True)
+    pad2 = fixed.batch([0, 3], torch.Generator().manual_seed(0))[4]
+    assert pad2[0].tolist() == [False] * 3 + [True] * 2 and pad2[1].tolist() == [False] + [True] * 4
+
+
+def test_front_half_equals_the_recorded_reference_split(tmp_path):
+    import pandas as pd
+    z = np.load(os.path.join(GOLDEN, "aux_loader_split.npz"), allow_pickle=False)
+    spec = {k[5:]: z[k] for k in z.files if k.startswith("spec/")}
+    root = Path(tmp_path)
+    case_ids = [str(c) for c in spec["case_ids"]]
+    pd.DataFrame(spec["expr"], index=case_ids, columns=[str(g) for g in spec["gene_names"]]).to_parquet(root / "rna_seq.parquet")
+    (root / "case_ids.txt").write_text("\n".join(str(c) for c in spec["listed_case_ids"]) + "\n")
+    txt = [str(c) for c in spec["text_case_ids"]]
+    pd.DataFrame(np.zeros((len(txt), 2), dtype=np.float32), index=txt).rename(columns=str).to_parquet(root / "text_emb.parquet")
+    (root / "patch_emb").mkdir(); (root / "token_emb").mkdir()
+    for i, cid in enumerate(str(c) for c in spec["patch_case_ids"]):
+        np.save(root / "patch_emb" / f"{cid}.npy", spec["patches"][spec["patch_off"][i]:spec["patch_off"][i + 1]])
+        np.save(root / "token_emb" / f"{cid}.npy", spec["tokens"][i][None])
+        np.save(root / "token_emb" / f"{cid}_attention_mask.npy", spec["token_mask"][i][None])
+    with open(root / "metainfos.pkl", "wb") as f:
+        pickle.dump({str(c): {"disease_type": str(d), "primary_site": str(s)}
+                     for c, d, s in zip(spec["case_ids"], spec["disease"], spec["site"])}, f)
+    tr, va, te, n_genes = dataloader_multi_patch_conditional_gan(
+        root, batch_size=4, num_workers=0, num_patches=3, text_embedding_file="text_emb.parquet",
+        patch_embeddings_folder="patch_emb", token_embeddings_folder="token_emb", device="cpu")
+    assert n_genes == int(z["n_genes"])
+    for name, loader in (("train", tr), ("validation", va), ("test", te)):
+        ds = loader.dataset
+        assert [str(c) for c in ds.case_ids] == [str(c) for c in z[f"{name}/case_ids"]], name
+        assert np.allclose(ds.gene_expressions.numpy(), z[f"{name}/gene_expressions"].astype(np.float32), rtol=1e-6, atol=1e-6)
+        assert np.array_equal(ds.disease_types.numpy(), z[f"{name}/disease_types"])
+        assert np.array_equal(ds.primary_site.numpy(), z[f"{name}/primary_site"])
+        assert len(loader) == int(z[f"{name}/n_batches"])
+    b = next(iter(tr))
+    assert b[3].shape == (4, 3, spec["patches"].shape[1]) and b[2].shape == (4, n_genes) and not b[4].any()
 
 
 def _write_cases(tmp_path, counts, Dp=6, T=5, Dt=4, G=7, seed=0):
@@ -44,9 +118,9 @@ def test_cache_reproduces_the_reference_item_semantics(tmp_path):
             assert not pad[b].any()
             hits = [(ref32 == patches[b, j]).all(dim=1).nonzero().flatten().tolist() for j in range(P)]
             assert all(len(h) == 1 for h in hits) and len({h[0] for h in hits}) == P
-        else:                                                               # D:36-40: file order, then zero rows with mask True
+        else:                                                               # D:36-40: file order, then zero rows; mask all False
             assert torch.equal(patches[b, :n], ref32) and torch.equal(patches[b, n:], torch.zeros(P - n, 6))
-            assert torch.equal(pad[b], torch.tensor([False] * n + [True] * (P - n)))
+            assert not pad[b].any()
 
 
 def test_subsample_is_uniform_and_loader_covers_every_case_once_per_epoch(tmp_path):

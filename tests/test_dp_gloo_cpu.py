@@ -33,6 +33,12 @@ class OracleEngine:
         self.flat = {r: {"g": torch.zeros(sum(p.numel() for _, p in live_parameters(n)))} for r, n in self.nets.items()}
         self.losses = torch.zeros(L.N_LOSSES)
         self.lr = {}
+        # the MLP-head parameters (<mlp>.0.0, <mlp>.1.0, final_layer) are the last six entries of the flat layout
+        self.mlp_range = {}
+        for r, n in self.nets.items():
+            sizes = [p.numel() for _, p in live_parameters(n)]
+            self.mlp_range[r] = (sum(sizes[:-6]), sum(sizes[-6:]))
+        self.calls = []
 
     def set_lr(self, role, lr):
         self.lr[role] = lr
@@ -56,6 +62,24 @@ class OracleEngine:
         # undo the oracle's in-place clipping: store the raw gradients
         self._store(L.ROLE_CRITIC, r["grads"])
         self.losses[0], self.losses[1], self.losses[2] = r["d_real"].item(), r["d_fake"].item(), r["gp"].item()
+
+    # two-phase form used by the data-parallel host loop: the stand-in has the whole gradient after "head"
+    def critic_backward_head(self, x, z, alpha, pat, ppad, text, tpad):
+        self.calls.append(("critic_head", z.clone()))
+        self.critic_backward(x, z, alpha, pat, ppad, text, tpad)
+
+    def critic_backward_cond(self, pat, ppad, text, tpad):
+        self.calls.append(("critic_cond",))
+
+    def critic_cond_prefetch(self, pat, ppad, text, tpad):
+        self.calls.append(("critic_cond_prefetch", pat.clone()))
+
+    def generator_backward_head(self, z, pat, ppad, text, tpad):
+        self.calls.append(("gen_head", z.clone()))
+        self.generator_backward(z, pat, ppad, text, tpad)
+
+    def generator_backward_cond(self, pat, ppad, text, tpad):
+        self.calls.append(("gen_cond",))
 
     def critic_apply(self, scale):
         self._apply(L.ROLE_CRITIC, scale, self.tr.cfg.clip_d, self.tr.opt_d)
@@ -111,10 +135,18 @@ def _worker(rank, world, port, q):
         n = B // world
         s = slice(rank * n, (rank + 1) * n)
         w.train_with_noise(x[s], text[s], text_pad[s], patches[s], patch_pad[s], z_all[:, s].contiguous(),
-                           alpha_all[:, s].contiguous())
+                           alpha_all[:, s].contiguous(), next_cond=(patches[s], patch_pad[s], text[s], text_pad[s]))
+        order = [c[0] for c in w.engine.calls]
+        assert order == ["critic_head", "critic_cond"] * CFG.n_critic + ["gen_head", "gen_cond", "critic_cond_prefetch"], order
         sd = {k: v.detach().numpy().copy() for k, v in {**{"g." + k: v for k, v in tr.gen.state_dict().items()},
                                                          **{"d." + k: v for k, v in tr.disc.state_dict().items()}}.items()}
-        q.put((rank, sd, float(w.d_batch_loss[0])))
+        d_loss_global = float(w.d_batch_loss[0])
+        # train() draws its own noise: every rank must use a different z / alpha stream (SURVEY 8e partitioning)
+        torch.manual_seed(123)
+        w.engine.calls.clear()
+        w.train(x[s], text[s], text_pad[s], patches[s], patch_pad[s])
+        z0 = [c[1] for c in w.engine.calls if c[0] == "critic_head"][0]
+        q.put((rank, sd, d_loss_global, z0.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -137,7 +169,12 @@ def test_two_ranks_equal_one_rank_full_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    sds = {r: sd for r, sd, _ in got}
+    sds = {r: sd for r, sd, _, _ in got}
+    zs = {r: z for r, _, _, z in got}
+    assert zs[0].shape == zs[1].shape and not np.allclose(zs[0], zs[1]), "ranks drew identical latent vectors"
+    # reported losses are global means (identical on both ranks)
+    dl = {r: d for r, _, d, _ in got}
+    assert abs(dl[0] - dl[1]) <= 1e-6 * max(1.0, abs(dl[0])), dl
     E = CFG.embedding_dims
     for k, v in ref.items():
         if "patches_transformer_layer." in k:

@@ -44,6 +44,10 @@ CASES = {
     # the longest sequence the key-streaming kernels take (64 key tiles), ragged tail
     "long_S2047": dict(cfg=PathConfig(n_genes=40, latent_dims=8, embedding_dims=64, hidden_dims=16, text_dims=16,
                                       patch_dims=24, dropout=0.0), B=1, P=2046, T=1),
+    # image-transformer sibling with S > 512: the key-streaming attention kernels under GG_VARIANT_IMG (BASELINE configs[4] has
+    # S = 1025), Linear-ReLU-LayerNorm patch encoder, bias-free layers, ragged masks
+    "img_long_S577_E256": dict(cfg=img_config(n_genes=48, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=20,
+                                              patch_dims=48, dropout=0.0), B=2, P=576, T=1),
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
@@ -168,6 +172,57 @@ def test_full_size_properties_cfg3():
     ck.done()
 
 
+def test_full_size_properties_cfg5_rank():
+    """Per-GPU shape of BASELINE configs[4] (conditional_gan_img_transformer.py: B = 128 per rank, 18 000 genes, 1 024 patch
+    tokens -> S = 1 025, the key-streaming attention kernels), bf16 mode as that configuration runs: (1) finite outputs and
+    gradients; (2) critic rows independent of the batch composition; (3) data-parallel identity (mean of the shard
+    gradients == full-batch gradient); (4) the fused long-sequence attention route against the unfused GEMM + softmax +
+    GEMM route of the same mode; (5) |grad_x^| against the row norms of the stored gradient."""
+    cfg = img_config(n_genes=18000, dropout=0.0)
+    B, P, T = 128, 1024, 1
+    torch.manual_seed(3)
+    tr = Trainer(cfg)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+    eng.set_precision("bf16")
+    load_oracle_state(eng, tr)
+    x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=9, pad_patches=True))
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    ck = Checker("full-size cfg5-per-rank properties (img variant, bf16)", 1e-3)
+    full = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
+    h = B // 2
+    half = eng.forward(L.ROLE_CRITIC, x[h:].contiguous(), patches[h:].contiguous(), patch_pad[h:].contiguous(),
+                       text[h:].contiguous(), text_pad[h:].contiguous(), train=False)
+    assert torch.isfinite(full).all()
+    ck.check("critic rows independent of batch", half, full[h:], tol=1e-4)
+    xgen = eng.forward(L.ROLE_GENERATOR, z, patches, patch_pad, text, text_pad, train=False)
+    assert tuple(xgen.shape) == (B, 18000) and torch.isfinite(xgen).all()
+    eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+    gfull = eng.flat[L.ROLE_CRITIC]["g"].clone()
+    lfull = eng.losses.clone()
+    nrm = eng.debug_buffer("gp_grad").view(B, -1).norm(dim=1)
+    ck.check("|grad_x_hat| vs gp_nrm2", nrm ** 2, eng.debug_buffer("gp_nrm2"), tol=1e-5)
+    assert torch.isfinite(gfull).all() and torch.isfinite(lfull).all()
+    acc = torch.zeros_like(gfull)
+    for s in (slice(0, h), slice(h, B)):
+        eng.critic_backward(x[s].contiguous(), z[s].contiguous(), alpha[s].contiguous(), patches[s].contiguous(),
+                            patch_pad[s].contiguous(), text[s].contiguous(), text_pad[s].contiguous())
+        acc += eng.flat[L.ROLE_CRITIC]["g"]
+    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=5e-4)
+    eng.set_flash(False)                      # unfused attention route of the same precision mode
+    unf = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
+    ck.check("critic score: key-streaming attention vs unfused", full, unf, tol=2e-2)
+    eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+    gunf = eng.flat[L.ROLE_CRITIC]["g"]
+    cs = _cos(gfull, gunf)
+    from gpu_util import diag
+    diag(f"   flat critic gradient cosine, key-streaming vs unfused attention at S = 1025: {cs:.5f}")
+    assert cs >= 0.995, cs
+    ck.check("losses: key-streaming vs unfused", lfull[:3], eng.losses[:3], tol=2e-2)
+    ck.done()
+
+
 def test_dropout_statistics_and_replicas():
     """p=0.1: attention-probability dropout zeroes ~10 % of the unmasked probabilities, survivors are
     scaled by 1/(1-p); the three critic passes of one iteration draw independent masks; backward
@@ -248,7 +303,8 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
     ck.done()
 
 
-@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256", "long_S2047"])
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256", "long_S2047",
+                                  "img_long_S577_E256"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_flash_attention_matches_unfused_path(case, dropout):
     """Fused attention forward/backward (attention.hip) against the unfused bf16 path (GEMM + softmax +
@@ -499,7 +555,7 @@ def test_side_streams_do_not_change_results(case):
 
 
 @pytest.mark.parametrize("case", ["mid_T5_ragged", "leaky_T300", "single_sample", "long_S601", "text_T77_E256", "film_P1",
-                                  "film_P33_E256", "img_P40_E256", "long_S545_E256"])
+                                  "film_P33_E256", "img_P40_E256", "long_S545_E256", "img_long_S577_E256"])
 def test_bf16_mode_on_generic_shapes(case):
     """bf16 mode on shapes that do not qualify for the fused kernels (E = 32: head dim 8, no token-on-lane / flash path;
     one-sample batches): the generic bf16 GEMM route must still follow the fp32 oracle's gradient direction."""

@@ -75,3 +75,33 @@ def test_prdc_matches_the_reference_arithmetic(shape, k):
     tol = 2.5 / min(nr, nf)                                      # a comparison at a float32 / float64 tie may fall either way
     for name in ("precision", "recall", "density", "coverage"):
         assert abs(got[name] - ref[name]) <= tol * max(1.0, ref[name]), (name, got[name], ref[name])
+
+
+# ---- pinned by outputs of the REAL reference functions (tests/golden/aux_*.npz, oracle/make_golden_aux.py) -------------------
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_prdc_equals_the_recorded_reference_values():
+    """src/distribution_distances.py:102-142 compute_prdc run by the reference itself on the stored features."""
+    z = np.load(os.path.join(GOLDEN, "aux_prdc.npz"))
+    for k in (1, 5, 10):
+        got = evaluate.compute_prdc(z["real"], z["fake"], k)
+        want = dict(zip(("precision", "recall", "density", "coverage"), z[f"k{k}"]))
+        for name, w in want.items():
+            assert abs(got[name] - w) <= 1e-9 + 1e-12 * abs(w), (k, name, got[name], w)      # counts: exact
+
+
+def test_knn_precision_recall_equals_the_recorded_reference_values():
+    """src/unsupervised_metrics.py:141-323: ManifoldEstimator radii / membership and get_precision_recall."""
+    z = np.load(os.path.join(GOLDEN, "aux_knn_pr.npz"))
+    for k in (3, 10):
+        est = evaluate.ManifoldEstimator(z["real"], nhood_sizes=[k])
+        assert np.allclose(est.D, z[f"k{k}/radii_real"], rtol=2e-4, atol=1e-5)             # squared radii (the reference's
+        pred = est.evaluate(z["fake"])                                                      # |u|^2-2uv+|v|^2 form cancels in fp32)
+        assert np.array_equal(pred, z[f"k{k}/fake_in_real_manifold"])
+        p, r = evaluate.get_precision_recall(z["real"], z["fake"], nb_nn=[k])
+        assert (p, r) == pytest.approx(tuple(z[f"k{k}/precision_recall"]), abs=1e-12)
+        st = evaluate.knn_precision_recall_features(z["real"], z["fake"], nhood_sizes=[k])
+        assert st["precision"].shape == (1,) and st["recall"].shape == (1,)

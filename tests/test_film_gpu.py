@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from gemm_gan_amd import film, img_transformer
-from golden_util import Golden
+from golden_util import Golden, comparable
 from gpu_util import Checker
 
 pytestmark = pytest.mark.gpu
@@ -43,19 +43,17 @@ def test_state_dict_keys_and_golden_train_step(name):
     alpha_all = g.t("step_rms_prop/alpha").cuda().reshape(z_all.shape[0] - 1, -1).contiguous()
     w.train_with_noise(x, text.contiguous(), text_pad, patches.contiguous(), patch_pad, z_all, alpha_all)
     # several normalised-gradient steps: same gates as tests/test_engine_golden_gpu.py::test_full_train_step
-    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"], tol=5e-3)
-    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]), tol=5e-3)
-    lr = 5e-4
+    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"])
+    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]))
     for role, net in (("gen", w.gen), ("disc", w.disc)):
         sd = net.state_dict()
         steps = 1 if role == "gen" else g.dims["n_critic"]
         for n, ref in g.group(f"step_rms_prop/post_{role}").items():
             if n.startswith("patches_transformer_layer."):
                 continue
-            got = sd[n].detach().cpu().numpy().reshape(-1)
-            init = g.z[f"init_{role}/{n}"].reshape(-1)
-            err = np.abs(got - ref.reshape(-1)).max()
-            assert err <= 0.25 * steps * lr * 10 + 1e-3 * np.abs(ref - init.reshape(ref.shape)).max() + 1e-6, (role, n, err)
+            keep = comparable(n, sd[n], g.dims["E"])
+            ck.check_post(f"post {role} {n}", sd[n].detach().cpu().numpy().reshape(-1)[keep], ref.reshape(-1)[keep],
+                          g.z[f"init_{role}/{n}"].reshape(-1)[keep], "rms_prop", 5e-4, steps)
     ck.done()
 
 
@@ -81,8 +79,11 @@ def test_reference_call_signatures_and_fit(tmp_path):
     assert len(hist["d loss"]) == 2 and all(np.isfinite(v) for v in hist["d loss"] + hist["g loss"])
     sd = torch.load(tmp_path / "generator_last_epoch.pt")
     assert set(sd) == set(g.group("init_gen"))                  # a checkpoint the reference's load_state_dict accepts
-    with pytest.raises(NotImplementedError):
-        w.gradient_penalty(x, x, emb, patches, patch_pad)
+    # F:322-345 gradient_penalty(real, fake, text_embedding, patches, padding_mask): real == fake makes the interpolate
+    # independent of alpha, so the value equals the penalty of the critic at x, whatever torch.rand draws
+    gp = w.gradient_penalty(x, x, emb, patches, patch_pad)
+    gp2 = w.gradient_penalty(x, x, emb, patches, patch_pad)
+    assert gp.dim() == 0 and float(gp) >= 0.0 and abs(float(gp) - float(gp2)) <= 1e-5 * max(1.0, float(gp))
 
 
 def test_vanilla_mirror_golden_train_step(tmp_path):
@@ -109,15 +110,14 @@ def test_vanilla_mirror_golden_train_step(tmp_path):
     z_all = g.t("step_rms_prop/z").cuda().contiguous()
     alpha_all = g.t("step_rms_prop/alpha").cuda().reshape(z_all.shape[0] - 1, -1).contiguous()
     w.train_with_explicit_noise(x, z_all, alpha_all)
-    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"], tol=5e-3)
-    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]), tol=5e-3)
+    ck.check("d_batch_loss", w.d_batch_loss, g.z["step_rms_prop/d_batch_loss"])
+    ck.check("gen_loss", np.array([float(w.gen_loss)]), np.array([float(g.z["step_rms_prop/gen_loss"])]))
     for role, net in (("gen", w.gen), ("disc", w.disc)):
         sd = net.state_dict()
         steps = 1 if role == "gen" else d["n_critic"]
         for n, ref in g.group(f"step_rms_prop/post_{role}").items():
-            err = np.abs(sd[n].detach().cpu().numpy().reshape(-1) - ref.reshape(-1)).max()
-            move = np.abs(ref.reshape(-1) - g.z[f"init_{role}/{n}"].reshape(-1)).max()
-            assert err <= 0.25 * steps * 5e-3 + 1e-3 * move + 1e-6, (role, n, err)
+            ck.check_post(f"post {role} {n}", sd[n].detach().cpu().numpy().reshape(-1), ref.reshape(-1),
+                          g.z[f"init_{role}/{n}"].reshape(-1), "rms_prop", 5e-4, steps)
     # the padded columns of the engine's first-layer weights are still exactly zero after six optimiser steps
     for role in (0, 1):
         name = [k for k in w.engine.layout[role] if k.endswith(".0.0.weight")][0]

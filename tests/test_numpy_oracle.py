@@ -57,9 +57,9 @@ def test_critic_iteration_vs_golden(name):
     opt = no.Optim("rms_prop", 5e-4)
     opt.step(pd, {n: v * coef for n, v in grads.items()})
     for n, r in g.group("critic1/post_disc").items():
-        keep = comparable(n, pd[n], g.dims["E"])[::3]
+        keep = comparable(n, pd[n], g.dims["E"])
         # first RMSprop step == -lr*g/(0.1|g|+1e-8): entries with |g|~1e-7 amplify fp32-vs-fp64 noise
-        assert rel_err(pd[n].reshape(-1)[::3][keep], r[keep]) < 1e-3, n
+        assert rel_err(pd[n].reshape(-1)[keep], r.reshape(-1)[keep]) < 1e-3, n
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -88,14 +88,77 @@ def test_full_step_vs_golden(name, opt):
     losses, g_loss = no.train_step(pg, pd, no.Optim(opt, 5e-4), no.Optim(opt, 5e-4), x, cond, list(zs), list(al), slope=g.slope)
     assert rel_err([losses["d_loss"], losses["d_real"], losses["d_fake"]], g.z[f"step_{opt}/d_batch_loss"]) < 1e-4
     assert abs(g_loss - float(g.z[f"step_{opt}/gen_loss"])) < 1e-4
-    stride = 1 if opt == "rms_prop" else 5
-    # RMSprop/Adam normalise tiny gradients to +-lr steps: compare the UPDATE relative to lr
+    # Every element of every post-step tensor (no subsampling).  RMSprop / Adam divide by |g|: an entry whose true gradient
+    # is rounding noise moves by +-lr per step in ANY implementation (its sign is noise), so the gate has two parts:
+    # all but a small share of the entries agree to 1e-3 of the tensor's largest update, and no entry is off by more than
+    # the optimiser's largest possible travel.
+    lr = 5e-4
     for role, p in (("gen", pg), ("disc", pd)):
         init = g.group(f"init_{role}")
+        steps = 1 if role == "gen" else g.dims["n_critic"]
         for n, r in g.group(f"step_{opt}/post_{role}").items():
-            keep = comparable(n, p[n], g.dims["E"])[::stride]
-            a = p[n].reshape(-1)[::stride][keep]
-            assert np.abs(a - r.reshape(-1)[keep]).max() < 2e-4 * max(np.abs(r).max(), 1e-3) + 1e-6, (role, n)
+            keep = comparable(n, p[n], g.dims["E"])
+            a, r = p[n].reshape(-1)[keep], r.reshape(-1)[keep]
+            move = np.abs(r - init[n].reshape(-1)[keep]).max()
+            err = np.abs(a - r)
+            assert err.max() <= 2.2 * steps * lr, (role, n, err.max())
+            bad = int((err > 1e-3 * move + 1e-7).sum())
+            assert bad <= max(2, 0.03 * err.size), (role, n, bad, err.size)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_multi_step_conditioning(name):
+    """How far does fp32 rounding noise in the gradients move the result of one train() (n_critic + 1 normalised-gradient
+    optimiser steps)?  The float64 oracle's gradients are perturbed before every step:
+      (a) 1e-6 RELATIVE noise on every entry, and (b) ABSOLUTE noise of 1e-6 of the tensor's largest entry on the entries
+      that are not structurally zero - fp32 summation-order noise looks like (b): losses move by < 1e-4 relative, so the
+      multi-step loss gates of the GPU tests (1e-3, tests/test_engine_golden_gpu.py::test_full_train_step) are honest;
+      (c) the same absolute noise on EVERY entry, including the structurally zero ones (dead ReLU units, the key-bias
+      slice): RMSprop's first step is 10 lr sign(g) whatever |g| is, so noise on a zero gradient is a full-size step and the
+      losses move by percents.  Both implementations produce exact zeros there, so (c) does not occur - but it is why
+      post-step PARAMETERS are gated by "all but a few entries" + "nobody beyond the optimiser's travel" instead of
+      elementwise (see the comment in test_full_step_vs_golden)."""
+    g = Golden(name)
+    x, cond = _np_inputs(g)
+    zs = list(g.z["step_rms_prop/z"].astype(np.float64))
+    al = list(g.z["step_rms_prop/alpha"].astype(np.float64))
+    E = g.dims["E"]
+
+    def run(hook):
+        pd = no.params_from_state(g.group("init_disc"))
+        pg = no.params_from_state(g.group("init_gen"))
+        losses, g_loss = no.train_step(pg, pd, no.Optim("rms_prop", 5e-4), no.Optim("rms_prop", 5e-4), x, cond, zs, al,
+                                       slope=g.slope, grad_hook=hook)
+        return np.array([losses["d_real"], losses["d_fake"], g_loss])
+
+    base = run(None)
+
+    def worst(make_hook):
+        w = 0.0
+        for seed in range(3):
+            w = max(w, float(np.abs(run(make_hook(np.random.default_rng(seed))) - base).max() / np.abs(base).max()))
+        return w
+
+    def absolute(rng, only_nonzero):
+        def hook(gr):
+            out = {}
+            for k, v in gr.items():
+                n = 1e-6 * np.abs(v).max() * rng.standard_normal(v.shape)
+                if only_nonzero:
+                    n = n * (v != 0)
+                    if k.endswith("in_proj_bias"):
+                        n.reshape(-1)[E:2 * E] = 0          # zero by shift invariance of the softmax
+                out[k] = v + n
+            return out
+        return hook
+
+    rel = worst(lambda rng: (lambda gr: {k: v * (1.0 + 1e-6 * rng.standard_normal(v.shape)) for k, v in gr.items()}))
+    nz = worst(lambda rng: absolute(rng, True))
+    every = worst(lambda rng: absolute(rng, False))
+    print(f"{name}: loss change after one train(): relative noise {rel:.1e}, absolute on non-zero entries {nz:.1e}, "
+          f"absolute on every entry {every:.1e}")
+    assert rel < 1e-6 and nz < 1e-4
+    assert every > 10 * nz
 
 
 def test_vs_torch_autograd_other_shape():

@@ -83,7 +83,7 @@ def test_critic_iteration(name):
         assert r["grads"][n] is None
     post = tr.disc.state_dict()
     for n, ref in g.group("critic1/post_disc").items():
-        assert rel_err(post[n].reshape(-1)[::3], ref) < 1e-5, n
+        assert rel_err(post[n].reshape(-1), ref.reshape(-1)) < 1e-5, n
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -96,7 +96,7 @@ def test_generator_iteration(name):
         assert rel_err(r["grads"][n], ref) < 1e-5, n
     post = tr.gen.state_dict()
     for n, ref in g.group("gen1/post_gen").items():
-        assert rel_err(post[n].reshape(-1)[::3], ref) < 1e-5, n
+        assert rel_err(post[n].reshape(-1), ref.reshape(-1)) < 1e-5, n
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -113,8 +113,7 @@ def test_full_train_step(name, opt):
     c = out["critic"]
     assert rel_err([c["d_loss"].item(), c["d_real"].item(), c["d_fake"].item()], g.z[f"step_{opt}/d_batch_loss"]) < 1e-5
     assert abs(out["gen"]["g_loss"].item() - float(g.z[f"step_{opt}/gen_loss"])) < 1e-5
-    stride = 1 if opt == "rms_prop" else 5
     for role, net in (("gen", tr.gen), ("disc", tr.disc)):
         sd = net.state_dict()
         for n, ref in g.group(f"step_{opt}/post_{role}").items():
-            assert rel_err(sd[n].reshape(-1)[::stride], ref.reshape(-1)) < 2e-5, (role, n)
+            assert rel_err(sd[n].reshape(-1), ref.reshape(-1)) < 2e-5, (role, n)
