@@ -52,7 +52,11 @@ def parse():
                          "f32 = exact fp32-input MFMA (the 1e-3 parity mode)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra f32 parity-mode timing (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=8,
+                    help="minibatch of the CPU baseline sample (the default bench run is bounded to ~20 s of CPU work; "
+                         "--cpu-batch 256 --cpu-steps 1 times the full cfg3 minibatch once: minutes)")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="timed CPU steps (0: as many as fit in ~20 s, at most 12)")
+    ap.add_argument("--parity-steps", type=int, default=10, help="timed steps of the f32 reference-precision figure")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
     return ap.parse_args()
 
@@ -116,15 +120,24 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     step()
     warm = time.perf_counter() - t0
-    n = max(1, min(12, int(20.0 / max(warm, 1e-3))))      # about 20 s of CPU work
+    n = args.cpu_steps if args.cpu_steps > 0 else max(1, min(12, int(20.0 / max(warm, 1e-3))))      # about 20 s of CPU work
     log(f"cpu baseline: warm-up step {warm:.1f} s on {cores} threads, timing {n} step(s)")
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
-    return dict(value=round(Bc * n / dt, 3), unit="samples/s", cores=cores, kind="port",
-                sample=f"oracle/torch_oracle.py (stock torch CPU modules, fp32, dropout {args.dropout}), same workload at "
-                       f"minibatch {Bc}: 1 warm-up + {n} timed train() steps, {dt:.1f} s")
+    out = dict(value=round(Bc * n / dt, 3), unit="samples/s", cores=cores, kind="port",
+               sample=f"oracle/torch_oracle.py (stock torch CPU modules, fp32, dropout {args.dropout}), same workload at "
+                      f"minibatch {Bc}" + ("" if Bc == args.batch else f" (NOT the GPU run's {args.batch}: a bounded sample; "
+                      "per-sample CPU cost is flat in the minibatch, see full_batch)") +
+                      f": 1 warm-up + {n} timed train() steps, {dt:.1f} s")
+    try:        # the one-off measurement at the full minibatch (BASELINE.md section 2 protocol), committed under profiles/
+        full = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_B256.json")))
+        if args.variant == "xattn_film" and args.batch == 256 and args.genes == 5000 and args.patches == 256:
+            out["full_batch"] = full
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -184,13 +197,18 @@ def main():
         patch_pad[: int(round(B * args.pad_frac)), P - P // 4:] = True
     text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
 
+    w.measure_comm = world > 1
+
     def train_once():
         if vanilla:
             w.train(x)
         elif film:
             w.train(x, text[:, 0, :], patches, patch_pad)
         else:
-            w.train(x, text, text_pad, patches, patch_pad)
+            # data parallel: the next step's conditioning inputs are known (here: the same synthetic shard), so the critic's
+            # first conditioning forward of the next step runs under this step's generator all-reduce
+            w.train(x, text, text_pad, patches, patch_pad,
+                    next_batch=(x, text, text_pad, patches, patch_pad) if world > 1 else None)
 
     def sync():
         if world > 1:
@@ -216,6 +234,8 @@ def main():
             w.engine.profile(False)
             w.engine.set_side_streams(True)
     sync()
+    if world > 1:
+        w.comm_wait_ms()                          # drop the warm-up's event pairs
     if prof:
         # The timed region carries event pairs for the DOMINANT class only (live roofline over the timed steps): an event
         # pair around each of the ~600 GEMM-class launches of a step costs 3 ms per step on the host-fed stream.
@@ -233,24 +253,36 @@ def main():
     if prof:
         rows = w.engine.profile_collect()
         w.engine.profile(False)
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    comm_ms = w.comm_wait_ms() / args.steps if world > 1 else 0.0
+    t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, comm_ms = float(t[0].item()), float(t[1].item())
     losses_head = (float(w.d_batch_loss[0]), float(w.g_batch_loss[0]))
+    gp_rows = None
+    if rank == 0 and prof:
+        # north_star: "achieved HBM GB/s on the GP kernel" - the four gradient-penalty kernels of csrc/gpchain.hip on the
+        # buffers of the last critic iteration, each timed by its own dispatch timestamps (20 launches)
+        gp_rows = [dict(kernel=r["kernel"], avg_launch_us=round(r["us"], 2), algorithmic_bytes=int(r["bytes"]),
+                        **{"GB/s": round(r["bytes"] / (r["us"] * 1e-6) / 1e9, 1),
+                           "frac_of_hbm_peak": round(r["bytes"] / (r["us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)})
+                   for r in w.engine.gp_profile(B)]
     parity = None
     if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-        # the exact-fp32 path (f32-input MFMA, the mode the 1e-3 parity tests run in), same workload, 1 warm-up + 2 steps
+        # the exact-fp32 path (f32-input MFMA, the mode the 1e-3 parity tests run in), same workload, 1 warm-up + N steps
         w.engine.set_precision("f32")
         train_once()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(args.parity_steps):
             train_once()
         torch.cuda.synchronize(dev)
-        pdt = (time.perf_counter() - t1) / 2
+        pdt = (time.perf_counter() - t1) / args.parity_steps
         parity = {"dtype": "f32", "ms_per_step": round(pdt * 1e3, 3), "value": round(B / pdt, 2), "unit": "samples/s",
-                  "note": "exact fp32-input MFMA path; <=1e-3 vs the reference (tests/test_engine_golden_gpu.py)"}
+                  "steps": args.parity_steps,
+                  "note": "THE REFERENCE-PRECISION FIGURE: exact fp32-input MFMA path, the mode held to <= 1e-3 elementwise against "
+                          "the reference (tests/test_engine_golden_gpu.py); the headline `value` is the bf16-operand mode "
+                          "north_star prescribes, whose measured error bounds are in tests/test_bf16_parity_gpu.py"}
         w.engine.set_precision("bf16")
     finite = bool(torch.isfinite(w.engine.flat[0]["w"]).all() and torch.isfinite(w.engine.flat[1]["w"]).all())
 
@@ -267,7 +299,8 @@ def main():
                                       + f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
                                       f"n_critic=5, rms_prop, dropout {args.dropout}"
                                       + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
-                          "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count()},
+                          "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count(),
+                          "allreduce_wait_ms_per_step": round(comm_ms, 3) if world > 1 else None},
                "finite": finite,
                "losses": {"d": losses_head[0], "g": losses_head[1]}}
         if parity is not None:
@@ -279,20 +312,25 @@ def main():
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             peak_tf = PEAK_TFLOPS[args.precision]
             frac_m, frac_h = tf / peak_tf, gbs / PEAK_HBM_GBS
-            bound = "mfma" if frac_m >= frac_h else "hbm"
+            # which roof: the kernel's arithmetic intensity against the machine's ridge point (FLOP per HBM byte)
+            intensity = dom["flops"] / max(dom["bytes"], 1.0)
+            ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+            bound = "mfma" if intensity >= ridge else "hbm"
             traffic = pmc_traffic(dom["name"])
             iso = None
             for r in rows_all:
                 if r["name"] == dom["name"]:
                     ig = r["bytes"] / (r["ms"] * 1e-3) / 1e9
                     it = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                    iso = {"achieved": round(it if bound == "mfma" else ig, 2), "frac": round(max(it / peak_tf, ig / PEAK_HBM_GBS), 4),
+                    iso = {"achieved": round(it if bound == "mfma" else ig, 2),
+                           "frac": round(it / peak_tf if bound == "mfma" else ig / PEAK_HBM_GBS, 4),
                            "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches": r["launches"]}
             out["roofline"] = {"kernel": dom["name"], "bound": bound,
                                "achieved": round(tf if bound == "mfma" else gbs, 2),
                                "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
                                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                               "frac": round(max(frac_m, frac_h), 4), "traffic": traffic,
+                               "frac": round(frac_m if bound == "mfma" else frac_h, 4), "traffic": traffic,
+                               "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                                "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes, "
                                                "profiles/r01_pmc_traffic.json; algorithmic bytes per launch = "
                                                + str(round(dom["bytes"] / dom["launches"] / 1e6, 1)) + " MB",
@@ -306,6 +344,12 @@ def main():
                                        "In a rocprofv3 trace of the concurrent run the side-stream wgrad_kernel<true,false,false,false> "
                                        "shows a larger total: its durations include waiting for compute units the main chain holds",
                                "isolated": iso,
+                               "gp_chain": gp_rows,
+                               "gp_chain_note": "gradient-penalty kernels (R:351-374 closed form + double backward, 6 launches per critic "
+                                                "iteration incl. the dW1x weight-gradient and the split-K grad*W1x^T GEMM, which appear "
+                                                "under their own classes below); every tensor of the chain is <= B*G*4 = "
+                                                f"{B * G * 4 / 1e6:.1f} MB, i.e. <= {B * G * 4 / 8e6:.2f} us at the HBM peak: launch-latency-"
+                                                "bound by construction at this minibatch",
                                "all_gemm_classes_note": "one untimed warm-up step with event pairs on every class" if rows_all else
                                                         "timed region",
                                "all_gemm_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),

@@ -372,7 +372,7 @@ size_t carve(gg_engine* e, void* base) {
     e->gp_grad = a.take<float>(B * G); e->gp_nrm2 = a.take<float>(B); e->gp_coef = a.take<float>(B);
     e->gp_dg1 = a.take<float>(B * H); e->gp_dg2 = a.take<float>(B * H);
     e->dxfake = a.take<float>(B * G);
-    e->sumsq = a.take<float>(4);
+    e->sumsq = a.take<float>(2 * 1024 + 8);      // per network: <= 1024 partial sums of squares (k_sumsq); [2048..] scratch
     e->sPd = a.take<float>(RB * nh * S * S);
     e->sdP = a.take<float>(Rb * nh * S * S);
     e->sdqkv = a.take<float>(Rb * S * 3 * E);
@@ -1268,11 +1268,11 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
     gg_engine* e = c.e;
     GG_REQUIRE(n.w && n.g && n.s1, "network buffers not bound");
     GG_REQUIRE(e->cfg.optimizer == GG_OPT_RMSPROP || n.s2, "Adam needs the second state buffer");
-    float* ss = e->sumsq + n.role;
-    KL(k_fill(ss, 1, 0.f, c.st));
-    if (max_norm > 0.f) KL(k_sumsq(n.g, n.live, ss, c.st));
+    float* ss = e->sumsq + 1024 * n.role;
+    int n_partials = 0;
+    if (max_norm > 0.f) KL(k_sumsq(n.g, n.live, ss, &n_partials, c.st));
     n.step_t += 1;
-    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.live, e->cfg.optimizer, n.lr, max_norm, ss, grad_scale, n.step_t, c.st));
+    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.live, e->cfg.optimizer, n.lr, max_norm, ss, n_partials, grad_scale, n.step_t, c.st));
     return 0;
 }
 
@@ -1697,6 +1697,48 @@ int gg_gradient_penalty(gg_engine* e, const float* x_real, const float* x_fake, 
     GG_TRY(check_cond(e, in));
     Ctx c{e, (hipStream_t)stream};
     return gradient_penalty(c, x_real, x_fake, alpha, in, train, gp_out);
+}
+// bench.py: the gradient-penalty kernels on the buffers of the last critic iteration, `reps` times each, timed by their own
+// dispatch timestamps.  us[4] = average microseconds of gp_front_k, gp_grad_k, gp_coef_k, gp_tail_k; bytes[4] = their
+// algorithmic HBM bytes per launch.  Scratch outputs only (the tail adds into the gradient buffer, which the next
+// iteration zeroes).
+int gg_gp_profile(gg_engine* e, int B, int reps, double* us, double* bytes, void* stream) {
+    GG_REQUIRE(e && us && bytes && reps > 0 && B > 0 && B <= e->maxB, "bad argument");
+    GG_REQUIRE(e->ws && e->net[1].w, "engine not bound");
+    hipStream_t st = (hipStream_t)stream;
+    Net& D = e->net[GG_ROLE_CRITIC];
+    const int G = e->G, E = e->E, H = e->H;
+    const float slope = e->cfg.negative_slope;
+    const float* a1h = e->headD.a1 + 2L * B * H;
+    const float* a2h = e->headD.a2 + 2L * B * H;
+    hipEvent_t ev[2];
+    GG_CHECK_HIP(hipEventCreate(&ev[0]));
+    GG_CHECK_HIP(hipEventCreate(&ev[1]));
+    for (int k = 0; k < 4; ++k) {
+        double acc = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            gp_time_next(ev[0], ev[1]);
+            int rc = 0;
+            if (k == 0) rc = k_gp_front(a1h, a2h, D.w + D.w3, D.w + D.w2, e->gp_g1, e->gp_dg1, e->gp_nrm2, B, H, slope, st);
+            if (k == 1) rc = k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, st);
+            if (k == 2) rc = k_gp_coef_scale(e->gp_nrm2, e->gp_g1, e->gp_coef, e->gp_g1s, e->sumsq + 2048, B, H, e->cfg.gp_weight, st);
+            if (k == 3) rc = k_gp_tail(e->gp_dg1, e->gp_coef, a1h, a2h, D.w + D.w3, D.w + D.w2, D.g + D.w2, D.g + D.w3, B, H, slope, st);
+            if (rc != 0) return rc;
+            GG_CHECK_HIP(hipEventSynchronize(ev[1]));
+            float ms = 0.f;
+            GG_CHECK_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            acc += ms * 1e3;
+        }
+        us[k] = acc / reps;
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    const double BH = 4.0 * B * H, HH = 4.0 * H * H, BG = 4.0 * B * G, HG = 4.0 * H * G;
+    bytes[0] = 2 * BH + HH + 2 * BH;          // a1, a2, W2 -> g1, dg1pre
+    bytes[1] = BH + HG + BG;                  // g1, W1x -> grad (row norms by atomics)
+    bytes[2] = 3 * BH;                        // g1 -> g1s (+ B scalars)
+    bytes[3] = 3 * BH + 2 * HH;               // dg1pre, a1, a2, W2 -> dW2
+    return 0;
 }
 int gg_generator_backward_head(gg_engine* e, const float* z, const gg_cond* in, float* losses, void* stream) {
     GG_REQUIRE(e && z && losses, "null argument");

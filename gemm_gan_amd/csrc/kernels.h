@@ -124,6 +124,8 @@ int k_gp_coef_scale(const float* nrm2, const float* g1, float* coef, float* g1s,
 int k_gp_tail(const float* dg1pre, const float* coef, const float* a1, const float* a2, const float* w3, const float* W2, float* dW2,
               float* dw3, int B, int H, float slope, hipStream_t st);
 
+void gp_time_next(hipEvent_t begin, hipEvent_t end);     // the next k_gp_* launch stamps these at the kernel's own begin / end
+
 // fused self-attention (attention.hip): bf16 MFMA, no [S,S] tensor in HBM -----------------------------------
 bool flash_attn_supported(int S, int E, int nh);
 // qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S].
@@ -197,11 +199,13 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
 // dbias (optional): dbias[n] += sum_m dY[m, n] with dY as the kernel sees it (bf16 operand values) - the Linear's bias gradient
 
 // optimiser ---------------------------------------------------------------------------------------
-int k_sumsq(const float* x, long n, float* out /* += */, hipStream_t st);
+// partials[0 .. *n_partials) = per-workgroup sums of squares (<= 1024 slots, no atomics: deterministic)
+int k_sumsq(const float* x, long n, float* partials, int* n_partials, hipStream_t st);
 enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };
-// clip coefficient = min(1, max_norm/(sqrt(*sumsq)+1e-6)) when max_norm > 0, else 1.  grad_scale is
-// an extra factor applied to every gradient first (1/world_size after a sum all-reduce).
+// clip coefficient = min(1, max_norm/(sqrt(sum of the partials)+1e-6)) when max_norm > 0, else 1 (the partials are added in
+// one fixed order by every workgroup).  grad_scale is an extra factor applied to every gradient first (1/world_size after
+// a sum all-reduce).
 int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-               const float* sumsq, float grad_scale, int step_t, hipStream_t st);
+               const float* partials, int n_partials, float grad_scale, int step_t, hipStream_t st);
 
 }  // namespace gg

@@ -1166,7 +1166,11 @@ int k_gp_coef(const float* nrm2, float* coef, float* losses, int B, float gp_wei
 }
 
 // ---- optimiser -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void sumsq_k(const float* x, long n, float* out) {
+// Global gradient norm for clip_grad_norm_, DETERMINISTIC: every workgroup writes its partial sum to its own slot (no
+// atomics), the optimiser kernel's workgroups each add the slots up in one fixed order.  Data-parallel replicas therefore
+// compute bit-identical clip coefficients from their bit-identical all-reduced gradients and never drift apart.
+constexpr int SUMSQ_MAX_BLOCKS = 1024;
+__global__ __launch_bounds__(TPB) void sumsq_k(const float* x, long n, float* partials) {
     float s = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = x[i];
@@ -1179,18 +1183,33 @@ __global__ __launch_bounds__(TPB) void sumsq_k(const float* x, long n, float* ou
     if (threadIdx.x == 0) {
         float a = 0.f;
         for (int k = 0; k < TPB / 64; ++k) a += red[k];
-        atomicAdd(out, a);
+        partials[blockIdx.x] = a;
     }
 }
-int k_sumsq(const float* x, long n, float* out, hipStream_t st) {
-    sumsq_k<<<nblocks(n, TPB * 8, 1024), TPB, 0, st>>>(x, n, out);
+int k_sumsq(const float* x, long n, float* partials, int* n_partials, hipStream_t st) {
+    const int nb = nblocks(n, TPB * 8, SUMSQ_MAX_BLOCKS);
+    sumsq_k<<<nb, TPB, 0, st>>>(x, n, partials);
+    *n_partials = nb;
     GG_LAUNCH_CHECK();
 }
-__global__ void opt_step_k(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-                           const float* sumsq, float grad_scale, float bc1, float bc2s) {
+__global__ __launch_bounds__(TPB) void opt_step_k(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
+                                                   const float* partials, int n_partials, float grad_scale, float bc1, float bc2s) {
     float coef = grad_scale;
     if (max_norm > 0.f) {
-        const float total = sqrtf(*sumsq) * grad_scale;
+        __shared__ float red[TPB / 64];
+        __shared__ float tot;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_partials; i += TPB) s += partials[i];      // same order in every workgroup
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f;
+            for (int k = 0; k < TPB / 64; ++k) a += red[k];
+            tot = a;
+        }
+        __syncthreads();
+        const float total = sqrtf(tot) * grad_scale;
         coef *= fminf(1.f, max_norm / (total + 1e-6f));
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1212,10 +1231,10 @@ __global__ void opt_step_k(float* w, const float* g, float* s1, float* s2, long 
     }
 }
 int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-               const float* sumsq, float grad_scale, int step_t, hipStream_t st) {
+               const float* partials, int n_partials, float grad_scale, int step_t, hipStream_t st) {
     const float bc1 = 1.f - powf(0.9f, (float)step_t);
     const float bc2s = sqrtf(1.f - powf(0.99f, (float)step_t));
-    opt_step_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(w, g, s1, s2, n, kind, lr, max_norm, sumsq, grad_scale, bc1, bc2s);
+    opt_step_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(w, g, s1, s2, n, kind, lr, max_norm, partials, n_partials, grad_scale, bc1, bc2s);
     GG_LAUNCH_CHECK();
 }
 

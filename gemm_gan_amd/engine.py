@@ -301,5 +301,11 @@ class Engine:
             self._prof_ids[rows[-1]["name"]] = i
         return rows
 
+    def gp_profile(self, B, reps=20):
+        """[{kernel, us, bytes}] of the four gradient-penalty kernels (buffers of the last critic iteration)."""
+        us, by = (C.c_double * 4)(), (C.c_double * 4)()
+        L.check(self.lib.gg_gp_profile(self.h, int(B), int(reps), us, by, _stream()))
+        return [dict(kernel=n, us=us[i], bytes=by[i]) for i, n in enumerate(("gp_front_k", "gp_grad_k", "gp_coef_k", "gp_tail_k"))]
+
     def launch_count(self):
         return int(self.lib.gg_launch_count(self.h))

@@ -98,9 +98,12 @@ class WGAN_GP(_m.WGAN_GP):
         text, tpad = self._text(text_embedding, z.shape[0])
         return super().train_gen(z, text, tpad, patches, padding_mask)
 
-    def train(self, gene_expression, text_embedding, patches, padding_mask):
+    def train(self, gene_expression, text_embedding, patches, padding_mask, next_batch=None):
         text, tpad = self._text(text_embedding, gene_expression.shape[0])
-        return super().train(gene_expression, text, tpad, patches, padding_mask)
+        if next_batch is not None:          # (gene_expression, text_embedding, patches, padding_mask) of the following call
+            nt, ntp = self._text(next_batch[1], next_batch[0].shape[0])
+            next_batch = (next_batch[0], nt, ntp, next_batch[2], next_batch[3])
+        return super().train(gene_expression, text, tpad, patches, padding_mask, next_batch=next_batch)
 
     def generate_samples(self, gene_expression, text_embedding, patches, padding_mask):
         with torch.no_grad():

@@ -220,6 +220,9 @@ int gg_profile_enable(gg_engine* e, int on);
 int gg_profile_collect(gg_engine* e);            /* returns number of classes, <0 on error */
 int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* launches, double* ms,
                     double* flops, double* bytes);
+/* gradient-penalty kernels (csrc/gpchain.hip) on the buffers of the last critic iteration with batch B: us[4] / bytes[4] = average
+ * microseconds (the dispatches' own timestamps) and algorithmic HBM bytes per launch of gp_front_k, gp_grad_k, gp_coef_k, gp_tail_k */
+int gg_gp_profile(gg_engine* e, int B, int reps, double* us, double* bytes, void* stream);
 /* counters of the last gg_train_step / iteration: kernels launched */
 int64_t gg_launch_count(const gg_engine* e);
 

@@ -59,10 +59,10 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_global_batch(fixture, tmp_pa
         # fp32 summation order differs between one batch of 2B rows and two of B (+ the host all-reduce): entries whose
         # gradient is rounding noise move by up to lr per RMSprop step in either run, everything else agrees to ~1e-4 relative
         bound = 2e-3 * max(float(np.abs(v).max()), 1e-3) + 1e-6
-        frac_bad = float((d > bound).mean())
-        worst = max(worst, frac_bad)
+        n_bad = int((d > bound).sum())
+        worst = max(worst, n_bad / d.size)
         assert d.max() <= steps * lr * 2.5 + bound, (k, float(d.max()))
-        assert frac_bad <= 0.02, (k, frac_bad)
+        assert n_bad <= max(3, 0.05 * d.size), (k, n_bad, d.size)
     l0, l1 = got[0]["losses"], got[1]["losses"]
     assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7)                            # reported losses are global means
     assert np.allclose(l0, np.array(ref_losses), rtol=5e-3, atol=5e-4), (l0, ref_losses)

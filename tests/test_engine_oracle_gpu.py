@@ -151,7 +151,7 @@ def test_full_size_properties_cfg3():
     g = torch.Generator().manual_seed(1)
     z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
     alpha = torch.rand(B, generator=g).cuda()
-    ck = Checker("full-size cfg3 properties", 1e-3)
+    ck = Checker("full-size cfg3 properties", 1e-3, metric="max")
     full = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
     h = B // 2
     half = eng.forward(L.ROLE_CRITIC, x[h:].contiguous(), patches[h:].contiguous(), patch_pad[h:].contiguous(),
@@ -189,13 +189,14 @@ def test_full_size_properties_cfg5_rank():
     g = torch.Generator().manual_seed(1)
     z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
     alpha = torch.rand(B, generator=g).cuda()
-    ck = Checker("full-size cfg5-per-rank properties (img variant, bf16)", 1e-3)
+    ck = Checker("full-size cfg5-per-rank properties (img variant, bf16)", 1e-3, metric="max")
     full = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
     h = B // 2
     half = eng.forward(L.ROLE_CRITIC, x[h:].contiguous(), patches[h:].contiguous(), patch_pad[h:].contiguous(),
                        text[h:].contiguous(), text_pad[h:].contiguous(), train=False)
     assert torch.isfinite(full).all()
-    ck.check("critic rows independent of batch", half, full[h:], tol=1e-4)
+    # 18 000-term bf16 dot products whose split over workgroups depends on the row count: accumulation order only
+    ck.check("critic rows independent of batch", half, full[h:], tol=1e-3)
     xgen = eng.forward(L.ROLE_GENERATOR, z, patches, patch_pad, text, text_pad, train=False)
     assert tuple(xgen.shape) == (B, 18000) and torch.isfinite(xgen).all()
     eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
@@ -209,7 +210,7 @@ def test_full_size_properties_cfg5_rank():
         eng.critic_backward(x[s].contiguous(), z[s].contiguous(), alpha[s].contiguous(), patches[s].contiguous(),
                             patch_pad[s].contiguous(), text[s].contiguous(), text_pad[s].contiguous())
         acc += eng.flat[L.ROLE_CRITIC]["g"]
-    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=5e-4)
+    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=1e-3)
     eng.set_flash(False)                      # unfused attention route of the same precision mode
     unf = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
     ck.check("critic score: key-streaming attention vs unfused", full, unf, tol=2e-2)
@@ -280,7 +281,7 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
     z = torch.randn(B, cfg.latent_dims, generator=g)
     alpha = torch.rand(B, 1, generator=g)
     cond = (patches, patch_pad, text, text_pad)
-    ck = Checker(f"bf16 mode vs fp32 oracle (hot_tiles_E256, flash={flash})", 4e-2)
+    ck = Checker(f"bf16 mode vs fp32 oracle (hot_tiles_E256, flash={flash})", 4e-2, metric="max")
     r = tr.critic_iteration(x, z, alpha, cond, apply=False)
     xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
     eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
@@ -333,7 +334,7 @@ def test_flash_attention_matches_unfused_path(case, dropout):
         eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
         out[flash] = dict(losses=eng.losses.clone(), ctx0=eng.debug_buffer("D.L0.ctx"), ctx1=eng.debug_buffer("D.L1.ctx"),
                           c=eng.debug_buffer("D.c"), g=eng.flat[L.ROLE_CRITIC]["g"].clone())
-    ck = Checker(f"flash vs unfused bf16 {case} dropout={dropout}", 2e-2)
+    ck = Checker(f"flash vs unfused bf16 {case} dropout={dropout}", 2e-2, metric="max")
     a, b = out[True], out[False]
     ck.check("layer-0 attention context", a["ctx0"], b["ctx0"], tol=1e-2)
     ck.check("layer-1 attention context", a["ctx1"], b["ctx1"], tol=1e-2)
@@ -382,7 +383,7 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
         out[on]["gstate"] = {k: v.clone() for k, v in eng.state(L.ROLE_GENERATOR, "g").items()}
         for nme in gnames:
             out[on]["gen:" + nme] = eng.debug_buffer(nme)
-    ck = Checker(f"tlin vs tile GEMM (bf16) {case} dropout={dropout}", 2e-3)
+    ck = Checker(f"tlin vs tile GEMM (bf16) {case} dropout={dropout}", 2e-3, metric="max")
     a, b = out[True], out[False]
     for n in names:
         # qkv / h are stored in bf16 on the tlin path (2^-9 element rounding), fp32 on the tile-GEMM path
@@ -429,7 +430,7 @@ def test_bf16_operand_storage_is_numerically_transparent(case):
         eng.set_seed(5)
         eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
         out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(), **{n: eng.debug_buffer(n) for n in names})
-    ck = Checker(f"bf16 operand storage on vs off {case}", 6e-3)
+    ck = Checker(f"bf16 operand storage on vs off {case}", 6e-3, metric="max")
     a, b = out[True], out[False]
     for n in names:
         ck.check(n, a[n], b[n])
@@ -463,7 +464,7 @@ def test_weight_gradient_kernel_matches_split_k_gemm(case):
         eng.set_seed(5)
         eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
         out[on] = {k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()}
-    ck = Checker(f"wgrad kernel vs split-K GEMM {case}", 2e-3)
+    ck = Checker(f"wgrad kernel vs split-K GEMM {case}", 2e-3, metric="max")
     for k in out[True]:
         # encoder weights; the patch encoder, whose X operand is FiLM-modulated on the fly by the kernel; and the FiLM
         # generator, whose gradient comes from the kernel's per-sample contraction mode (no d(modulated input) tensor)
@@ -511,7 +512,7 @@ def test_generator_prefetch_equals_sequential_passes():
             eng.set_prefetch(mode == "step_prefetch")
             eng.train_step(x, patches, patch_pad, text, text_pad, z_all, alpha_all)
         res[mode] = dict(losses=eng.losses.clone(), wd=eng.flat[L.ROLE_CRITIC]["w"].clone(), wg=eng.flat[L.ROLE_GENERATOR]["w"].clone())
-    ck = Checker(f"generator prefetch vs sequential ({PREC}, dropout 0)", 5e-3)
+    ck = Checker(f"generator prefetch vs sequential ({PREC}, dropout 0)", 5e-3, metric="max")
     ck.check("run-to-run: losses", res["step_sequential_again"]["losses"], res["step_sequential"]["losses"])
     ck.check("run-to-run: critic parameters", res["step_sequential_again"]["wd"], res["step_sequential"]["wd"])
     for other in ("step_sequential", "host_loop"):
@@ -547,7 +548,7 @@ def test_side_streams_do_not_change_results(case):
         eng.generator_backward(z_all[n].contiguous(), patches, patch_pad, text, text_pad)
         gg = eng.flat[L.ROLE_GENERATOR]["g"].clone()
         res[side] = dict(gd=gd, gg=gg, losses=eng.losses.clone())
-    ck = Checker(f"side streams on vs off {case}", 1e-4)
+    ck = Checker(f"side streams on vs off {case}", 1e-4, metric="max")
     ck.check("critic gradient", res[True]["gd"], res[False]["gd"])
     ck.check("generator gradient", res[True]["gg"], res[False]["gg"])
     ck.check("losses", res[True]["losses"], res[False]["losses"])
@@ -569,7 +570,7 @@ def test_bf16_mode_on_generic_shapes(case):
     r = tr.critic_iteration(x, z, alpha, cond, apply=False)
     xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
     eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
-    ck = Checker(f"bf16 mode vs fp32 oracle ({case})", 6e-2)
+    ck = Checker(f"bf16 mode vs fp32 oracle ({case})", 6e-2, metric="max")
     l = eng.losses.tolist()
     ck.check("d_real,d_fake", np.array(l[:2]), np.array([r["d_real"].item(), r["d_fake"].item()]))
     grads = eng.state(L.ROLE_CRITIC, "g")

@@ -41,7 +41,7 @@ def operands(M, N, K, layA, layB, integer):
 @pytest.mark.parametrize("layA", [0, 1])
 @pytest.mark.parametrize("layB", [0, 1])
 def test_gemm_layouts_exact_integer(layA, layB):
-    ck = Checker(f"gemm exact integer layA={layA} layB={layB}", 0.0)
+    ck = Checker(f"gemm exact integer layA={layA} layB={layB}", 0.0, metric="max")
     for (M, N, K) in [(32, 32, 8), (128, 128, 32), (200, 136, 72), (257, 64, 257), (5, 37, 69), (300, 260, 100)]:
         Am, Bm, A, B = operands(M, N, K, layA, layB, True)
         out = run_gemm(A, B, M, N, K, layA, layB)
@@ -51,7 +51,7 @@ def test_gemm_layouts_exact_integer(layA, layB):
 
 @pytest.mark.parametrize("layA,layB", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_random_splitk_and_epilogues(layA, layB):
-    ck = Checker(f"gemm random/splitk/epilogue layA={layA} layB={layB}", 2e-5)
+    ck = Checker(f"gemm random/splitk/epilogue layA={layA} layB={layB}", 2e-5, metric="max")
     M, N, K = 260, 200, 1000
     Am, Bm, A, B = operands(M, N, K, layA, layB, False)
     ref = Am.double() @ Bm.double()
@@ -70,7 +70,7 @@ def test_gemm_random_splitk_and_epilogues(layA, layB):
 
 def test_gemm_hot_path_shapes():
     """cfg3 shapes: QKV projection slice, critic first layer (K=5000, split-K), weight-gradient reduction."""
-    ck = Checker("gemm hot-path shapes", 3e-5)
+    ck = Checker("gemm hot-path shapes", 3e-5, metric="max")
     for (M, N, K, la, lb, sk) in [(2570, 768, 256, 0, 0, 1), (512, 256, 5000, 0, 0, 20), (768, 256, 4112, 1, 1, 16),
                                   (512, 5000, 256, 0, 1, 1)]:
         Am, Bm, A, B = operands(M, N, K, la, lb, False)
@@ -83,7 +83,7 @@ def test_gemm_hot_path_shapes():
 def test_gemm_bf16_layouts_exact_integer(layA, layB):
     """bf16 MFMA twin: small integers are exact in bf16 and their sums exact in the fp32 accumulator, so
     the fragment / transpose-staging maps are checked bit for bit."""
-    ck = Checker(f"gemm_bf16 exact integer layA={layA} layB={layB}", 0.0)
+    ck = Checker(f"gemm_bf16 exact integer layA={layA} layB={layB}", 0.0, metric="max")
     for (M, N, K) in [(32, 32, 16), (128, 128, 64), (200, 136, 72), (257, 64, 257), (5, 37, 69), (300, 260, 200)]:
         Am, Bm, A, B = operands(M, N, K, layA, layB, True)
         out = run_gemm(A, B, M, N, K, layA, layB, kernel="gg_test_gemm_bf16")
@@ -95,7 +95,7 @@ def test_gemm_bf16_layouts_exact_integer(layA, layB):
 def test_gemm_bf16_random(layA, layB):
     """Random operands: the result must equal the fp64 product of the bf16-ROUNDED operands to fp32
     accumulation accuracy (this isolates kernel errors from the intended operand rounding)."""
-    ck = Checker(f"gemm_bf16 random/splitk/epilogue layA={layA} layB={layB}", 2e-5)
+    ck = Checker(f"gemm_bf16 random/splitk/epilogue layA={layA} layB={layB}", 2e-5, metric="max")
     M, N, K = 260, 200, 1000
     Am, Bm, A, B = operands(M, N, K, layA, layB, False)
     ref = Am.bfloat16().double() @ Bm.bfloat16().double()
@@ -115,7 +115,7 @@ def test_gemm_bf16_random(layA, layB):
 def test_gemm_small_layouts_exact_integer(layA, layB):
     """64x64-tile / one-shot-K kernel used for the few-tile products: exact-integer check of every layout,
     ragged sizes, K spanning several 256-deep slabs, split-K, epilogue."""
-    ck = Checker(f"gemm_small exact integer layA={layA} layB={layB}", 0.0)
+    ck = Checker(f"gemm_small exact integer layA={layA} layB={layB}", 0.0, metric="max")
     for (M, N, K, sk) in [(32, 32, 16, 1), (64, 64, 256, 1), (200, 136, 72, 1), (257, 64, 600, 1), (5, 37, 69, 1), (256, 256, 1000, 4)]:
         Am, Bm, A, B = operands(M, N, K, layA, layB, True)
         out = run_gemm(A, B, M, N, K, layA, layB, splitk=sk, kernel="gg_test_gemm_small")
