@@ -47,6 +47,11 @@ struct Net {
     // bf16 shadow copies of the 2-D conditioning-stack weights (same offsets as the flat fp32 buffer):
     // wb = W [rows][cols], wtb = W^T [cols][rows]; refreshed from the fp32 master at every public entry
     char *wb = nullptr, *wtb = nullptr;
+    // fp8 mode: e4m3 shadow of the same weights (tensor at byte offset 2 * flat offset), per-tensor exponents
+    char* w8 = nullptr;
+    unsigned* w8_amax = nullptr;
+    int* w8_exp = nullptr;
+    std::map<long, int> tab_index;      // flat offset -> entry of `tab`
     ShadowEntry* tab_dev = nullptr;
     std::vector<ShadowEntry> tab;
     int step_t = 0;
@@ -124,6 +129,7 @@ struct gg_engine {
     Net net[2];
     float dropout = 0.f;
     int precision = GG_PREC_F32;
+    bool fp8_fwd = false;      // GG_PREC_FP8: bf16 mode with e4m3 operands in the encoder layers' forward Linears
     bool xattn = true;         // text<->image cross attention (conditional_gan_cross_attention_with_film.py); false: CLS row (conditional_gan_film.py)
     bool enc_bias = true;      // encoder layers with biases (bias=False in conditional_gan_film.py:115)
     bool no_cond = false;      // unconditional model (vanilla_gan_unconditional.py): the conditioning vector is identically zero
@@ -292,6 +298,7 @@ void build_net(gg_engine* e, int role) {
     for (const ParamInfo& pi : n.ps) {
         if (pi.ndim != 2) continue;
         if (pi.off == n.w1 || pi.off == n.w2 || pi.off == n.w3) continue;
+        n.tab_index[pi.off] = (int)n.tab.size();
         n.tab.push_back(ShadowEntry{pi.off, pi.shape[0], pi.shape[1]});
     }
 }
@@ -355,6 +362,9 @@ size_t carve(gg_engine* e, void* base) {
         n.wb = a.take<char>((size_t)n.total * 2);
         n.wtb = a.take<char>((size_t)n.total * 2);
         n.tab_dev = a.take<ShadowEntry>(n.tab.size() + 1);
+        n.w8 = a.take<char>((size_t)n.total * 2);
+        n.w8_amax = a.take<unsigned>(n.tab.size() + 1);
+        n.w8_exp = a.take<int>(n.tab.size() + 1);
     }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
@@ -537,7 +547,24 @@ inline bool use_tlin(gg_engine* e) { return e->tlin_on && e->precision == GG_PRE
 int refresh_shadows(Ctx& c, Net& n) {
     if (!use_tlin(c.e) || n.tab.empty()) return 0;
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
+    if (c.e->fp8_fwd) {
+        GG_TRY(k_shadow_weights_fp8(n.w, n.w8, n.w8_amax, n.w8_exp, n.tab_dev, (int)n.tab.size(), c.st));
+        c.e->launches += 2;
+    }
     return 0;
+}
+// Switches a forward Linear of an encoder layer to e4m3 operands when the engine is in fp8 mode and an fp8 instantiation
+// takes the shape (otherwise the bf16 kernel runs): weights from the e4m3 shadow, activations quantised as x * 2^x_exp.
+// Activations entering these Linears are LayerNorm outputs, attention contexts and ReLU outputs - O(1) magnitudes - so a
+// static 2^3 keeps |x| <= 56 in range (the conversion clamps) with 2e-3 as the smallest normal value.
+constexpr int FP8_X_EXP = 3;
+void maybe_fp8(gg_engine* e, const Net& n, TlinP& t, long w_off) {
+    if (!e->fp8_fwd) return;
+    auto it = n.tab_index.find(w_off);
+    if (it == n.tab_index.end()) return;
+    TlinP f = t;
+    f.fp8 = 1; f.W = n.w8 + 2 * w_off; f.w_exp = n.w8_exp + it->second; f.x_exp = FP8_X_EXP;
+    if (tlin_fp8_supported(f)) t = f;
 }
 inline const void* WB(const Net& n, long off) { return n.wb + 2 * off; }      // bf16 W   at flat offset `off`
 inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    // bf16 W^T at flat offset `off`
@@ -555,6 +582,9 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
+            if (kc == 29) snprintf(nm, sizeof nm, "tlin_res16_kernel<8,256,true,1,true>");
+            else if (kc >= 30) snprintf(nm, sizeof nm, "tlin_str_kernel<256,false,true,%d,true>", kc - 30);
+            else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
             e->str_cls_name[id - 18] = nm;
         }
@@ -700,6 +730,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             const bool shared = share0 && l == 0;
             t.X = x_in; t.ldx = E; t.M = shared ? (long)B * S : RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
             t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E; t.y_bf16 = bst;
+            if (bst) maybe_fp8(e, n, t, lp.sa.inw);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
         }
@@ -734,6 +765,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
             t.res = x_in; t.ldres = E; t.res_rows = (share0 && l == 0) ? (long)B * S : RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
+            if (bst) maybe_fp8(e, n, t, lp.sa.ow);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.ctx, E, w + lp.sa.ow, E, w + lp.sa.ob, L.r1, E, (int)(RB * S), E, E));
@@ -745,6 +777,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
             t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
             t.y_bf16 = bst;
+            if (bst) maybe_fp8(e, n, t, lp.l1w);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
@@ -757,6 +790,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
             t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
+            if (bst) maybe_fp8(e, n, t, lp.l2w);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
                 GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
@@ -1581,8 +1615,9 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
     e->dropout = cfg->dropout;
     e->seed = cfg->seed;
-    GG_REQUIRE(cfg->precision == GG_PREC_F32 || cfg->precision == GG_PREC_BF16, "bad precision");
-    e->precision = cfg->precision;
+    GG_REQUIRE(cfg->precision == GG_PREC_F32 || cfg->precision == GG_PREC_BF16 || cfg->precision == GG_PREC_FP8, "bad precision");
+    e->precision = cfg->precision == GG_PREC_FP8 ? GG_PREC_BF16 : cfg->precision;
+    e->fp8_fwd = cfg->precision == GG_PREC_FP8;
     build_net(e, GG_ROLE_GENERATOR);
     build_net(e, GG_ROLE_CRITIC);
     e->net[GG_ROLE_GENERATOR].lr = cfg->lr_g;
@@ -1818,8 +1853,9 @@ int gg_set_dropout(gg_engine* e, float p) {
     return 0;
 }
 int gg_set_precision(gg_engine* e, int precision) {
-    GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16), "bad precision");
-    e->precision = precision;
+    GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16 || precision == GG_PREC_FP8), "bad precision");
+    e->precision = precision == GG_PREC_FP8 ? GG_PREC_BF16 : precision;
+    e->fp8_fwd = precision == GG_PREC_FP8;
     return 0;
 }
 int gg_set_side_streams(gg_engine* e, int on) {

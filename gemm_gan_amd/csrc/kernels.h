@@ -155,10 +155,14 @@ struct TlinP {
     int accumulate = 0;                             // y += previous content
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
+    // fp8 (OCP e4m3) operands: W points at the e4m3 shadow copy (ldw in elements), *w_exp (device) is its per-tensor
+    // power-of-two exponent (stored value = w * 2^w_exp), activations are quantised as x * 2^x_exp on load
+    int fp8 = 0; const int* w_exp = nullptr; int x_exp = 0;
     int dbg = 0;                                    // timing experiments only (GG_TLIN_DBG): 1 no stores, 2 no MFMA, 4 no weight loads, 8 no X loads
     unsigned long long* stamps = nullptr;           // tools/tlin_probe: 4 s_memtime stamps per workgroup (wave 0)
 };
 bool tlin_supported(const TlinP& p);
+bool tlin_fp8_supported(const TlinP& p);            // p.fp8 set and one of the fp8 instantiations takes the shape
 int tlin(const TlinP& p, hipStream_t st);
 void tlin_time_next(hipEvent_t begin, hipEvent_t end);     // the next tlin() launch stamps these at the kernel's own begin / end
 // 0 stream (K != 256), 1 resident 32-token, 2/3/4 resident 16-token (+res+LN / += / other),
@@ -167,6 +171,8 @@ int tlin_kernel_class(const TlinP& p);
 // bf16 shadow copies of the 2-D weights: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows], same offsets
 struct ShadowEntry { long off; int rows, cols; };
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
+// e4m3 shadow: w8[2*off + i] = e4m3(w[off + i] * 2^w_exp[entry]), w_exp[entry] = floor(log2(448 / max|w|)); amax: scratch [n_entries]
+int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 
 // single-query attention over un-projected keys/values (sqattn.hip) ------------------------------------------------
 bool sqx_supported(int S, int E, int nh);

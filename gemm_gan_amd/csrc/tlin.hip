@@ -129,6 +129,70 @@ __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, in
     }
 }
 
+// ---- fp8 (OCP e4m3) operand path ---------------------------------------------------------------------------------
+// F8 instantiations keep the structure of the bf16 kernels and change the operand format: activations are quantised to
+// e4m3 on their way into the wave-private slab (x * 2^x_exp, clamped to +-448), the weights come from an e4m3 shadow copy
+// (w * 2^w_exp, per tensor, *p.w_exp), and the products run on the block-scaled matrix instructions
+// v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4 - twice the bf16 rate at 4x the K per instruction - whose E8M0 scale
+// operands undo the two power-of-two scales inside the instruction (scale byte = 127 - exponent), so accumulators,
+// epilogues and outputs are exactly those of the bf16 kernels.  A lane's fragment is 32 CONSECUTIVE k (32 bytes): lane
+// (c, g) of a 16x16x128 holds k = 32 g .. 32 g + 31 of row / column c, lane (c, h) of a 32x32x64 k = 32 h .. 32 h + 31.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned cvt4_fp8(float a, float b, float c, float d, float sc) {
+    a = __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f);
+    b = __builtin_amdgcn_fmed3f(b * sc, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f);
+    d = __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+__device__ __forceinline__ i32x8 lds_frag32(const unsigned char* q) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(q), hi = *reinterpret_cast<const u32x4*>(q + 16);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+// rows [tok0, tok0+ROWS) x [k0, k0+W) of X (fp32 or bf16) as e4m3 bytes into the slab xs (row stride LD bytes)
+template <int W, int LD, bool XB, int ROWS>
+__device__ __forceinline__ void stage_x8(const TlinP& p, unsigned char* xs, int tok0, int last_tok, int k0, int lane, float sc) {
+    asm volatile("" : "+v"(tok0));
+    const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
+    if constexpr (XB) {
+        constexpr int LPR = W / 8, RPI = 64 / LPR, NLD = ROWS / RPI;
+        const int lrow = lane / LPR, lcol = 8 * (lane % LPR);
+        const unsigned ldb = (unsigned)p.ldx * 2u, cb = (unsigned)(k0 + lcol) * 2u;
+        u32x4 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const u32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[2 * j] = __builtin_bit_cast(float, v[i][j] << 16);
+                f[2 * j + 1] = __builtin_bit_cast(float, v[i][j] & 0xffff0000u);
+            }
+            u32x2 w = {cvt4_fp8(f[0], f[1], f[2], f[3], sc), cvt4_fp8(f[4], f[5], f[6], f[7], sc)};
+            *reinterpret_cast<u32x2*>(&xs[(RPI * i + lrow) * LD + lcol]) = w;
+        }
+    } else {
+        constexpr int LPR = W / 4, RPI = 64 / LPR, NLD = ROWS / RPI;
+        const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
+        const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
+        constexpr int GB = NLD < 8 ? NLD : 8;
+#pragma unroll
+        for (int b0 = 0; b0 < NLD; b0 += GB) {
+            f32x4 v[GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + i), last_tok) * ldb + cb));
+#pragma unroll
+            for (int i = 0; i < GB; ++i)
+                *reinterpret_cast<unsigned*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = cvt4_fp8(v[i][0], v[i][1], v[i][2], v[i][3], sc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+__device__ __forceinline__ float exp2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+
 // ---- resident: all N = 32*NT_RES accumulators in registers, K streamed in slices of KSL ------------------------
 // PRE: what the epilogue adds to the product, prefetched while the last slice is multiplied:
 //      0 nothing, 1 residual rows, 2 previous output (accumulate), 3 decided at run time (generic, branchy)
@@ -332,18 +396,21 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 // tile is 16 features x 16 tokens: lane = (token lane&15, feature quad lane>>4), four consecutive features per
 // register quad, so one store instruction writes 16 rows x 64 contiguous bytes.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int NT_RES, int KSL, bool XB, int PRE>
+template <int NT_RES, int KSL, bool XB, int PRE, bool F8 = false>
 __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
     constexpr int N = 32 * NT_RES;
     constexpr int NF = 2 * NT_RES;                     // 16-feature tiles
-    constexpr int WLD = KSL + 8;
-    constexpr int PIECES = KSL / 8;
+    constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
+    constexpr int WLD = F8 ? KSL + 32 : KSL + 8;       // elements per LDS row (weights and activations)
+    constexpr int PIECES = KSL * ESZ / 16;             // 16-byte pieces per weight row
     constexpr int WLOADS = (32 * PIECES + 255) / 256;
-    constexpr int KS32 = KSL / 32;
+    constexpr int KS32 = F8 ? KSL / 128 : KSL / 32;    // MFMA steps per K slice (fragments held)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* const Ws = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
-    __bf16* const Xs = Ws + 2 * 32 * WLD;                                   // [4][16*WLD]
-    float* const Ps = reinterpret_cast<float*>(Xs + 4 * 16 * WLD);          // bias | gamma | beta  [3][N]
+    unsigned char* const Wsb = smem_raw;                                    // [2][32*WLD] elements
+    unsigned char* const Xsb = Wsb + 2 * 32 * WLD * ESZ;                    // [4][16*WLD]
+    __bf16* const Ws = reinterpret_cast<__bf16*>(Wsb);
+    __bf16* const Xs = reinterpret_cast<__bf16*>(Xsb);
+    float* const Ps = reinterpret_cast<float*>(Xsb + 4 * 16 * WLD * ESZ);   // bias | gamma | beta  [3][N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
@@ -354,14 +421,14 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
     __bf16* const xs = Xs + wave * 16 * WLD;
 
     u32x4 wreg[WLOADS];
-    const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+    const unsigned char* Wpb = reinterpret_cast<const unsigned char*>(p.W);
     auto load_chunk = [&](int ks, int nt) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
             if ((32 * PIECES) % 256 == 0 || row < 32)
-                wreg[i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + ks * KSL + 8 * piece);
+                wreg[i] = *reinterpret_cast<const u32x4*>(Wpb + ((long)(nt * 32 + row) * p.ldw + ks * KSL) * ESZ + 16 * piece);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -369,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[buf * 32 * WLD + row * WLD + 8 * piece]) = wreg[i];
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Wsb[(buf * 32 * WLD + row * WLD) * ESZ + 16 * piece]) = wreg[i];
         }
     };
 
@@ -380,6 +447,10 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
         Ps[2 * N + i] = p.ln_g ? p.ln_b[i] : 0.f;
     }
     store_chunk(0);
+    // fp8: E8M0 scale bytes that undo the operand scales inside the instruction, activation scale for the staging
+    const int sc_w = F8 ? 127 - *p.w_exp : 0, sc_x = F8 ? 127 - p.x_exp : 0;
+    const float xscale = F8 ? exp2i(p.x_exp) : 1.f;
+    unsigned char* const xs8 = Xsb + wave * 16 * WLD;
 
     const int tok = tok0 + c;
     const bool valid = tok <= last_tok;
@@ -391,12 +462,14 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
     const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
 
     f32x4 acc[NF];
-    bf16x8 xf[KS32];
+    bf16x8 xf[F8 ? 1 : KS32];
+    i32x8 xf8[F8 ? KS32 : 1];
     f32x4 pre[NF];
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
-        stage_x<KSL, WLD, XB, 16>(p, xs, tok0, last_tok, ks * KSL, lane);
+        if constexpr (F8) stage_x8<KSL, WLD, XB, 16>(p, xs8, tok0, last_tok, ks * KSL, lane, xscale);
+        else stage_x<KSL, WLD, XB, 16>(p, xs, tok0, last_tok, ks * KSL, lane);
         if constexpr (PRE != PRE_NONE) {
             if (ks == nks - 1) {
 #pragma unroll
@@ -412,8 +485,13 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (F8) {
 #pragma unroll
-        for (int s = 0; s < KS32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(&xs[c * WLD + 32 * s + 8 * q]);
+            for (int s = 0; s < KS32; ++s) xf8[s] = lds_frag32(xs8 + c * WLD + 128 * s + 32 * q);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(&xs[c * WLD + 32 * s + 8 * q]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __syncthreads();     // chunk `chunk` is in Ws[chunk & 1] (and Ps on the first pass)
@@ -425,6 +503,14 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 if (ks == 0) acc[2 * nt + ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (F8) {
+                    const unsigned char* wsb8 = Wsb + buf * 32 * WLD + (16 * ft + c) * WLD + 32 * q;
+#pragma unroll
+                    for (int s = 0; s < KS32; ++s)
+                        acc[2 * nt + ft] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(lds_frag32(wsb8 + 128 * s), xf8[s], acc[2 * nt + ft],
+                                                                                             0, 0, 0, sc_w, 0, sc_x);
+                    continue;
+                }
                 const __bf16* wsb = Ws + buf * 32 * WLD + (16 * ft + c) * WLD + 8 * q;
 #pragma unroll
                 for (int s4 = 0; s4 < KS32 / 4; ++s4) {
@@ -512,17 +598,20 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
 // ---- stream: K <= 256 register-resident, N streamed 32 features at a time ----------------------------------------
 // EPI: 0 bias (+ReLU), 1 bias (+ReLU) + dropout, 2 bias + sign mask of a reference tensor, 3 decided at run time
 enum { EPI_BIAS = 0, EPI_DROP = 1, EPI_MASK = 2, EPI_ANY = 3 };
-template <int KSL, bool XB, bool YB, int EPI>
+template <int KSL, bool XB, bool YB, int EPI, bool F8 = false>
 __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     constexpr int XW = KSL < 128 ? KSL : 128;          // staging window (bounds LDS so two workgroups fit a CU)
-    constexpr int XLDW = XW + 8;
-    constexpr int WLD = KSL + 8;
-    constexpr int PIECES = KSL / 8;
+    constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
+    constexpr int XLDW = F8 ? XW + 32 : XW + 8;
+    constexpr int WLD = F8 ? KSL + 32 : KSL + 8;
+    constexpr int PIECES = KSL * ESZ / 16;
     constexpr int WLOADS = (32 * PIECES + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* const Ws = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
-    __bf16* const Xs = Ws + 2 * 32 * WLD;                                   // [4][32*XLDW]
-    float* const Ps = reinterpret_cast<float*>(Xs + 4 * 32 * XLDW);         // bias [N]
+    unsigned char* const Wsb = smem_raw;                                    // [2][32*WLD] elements
+    unsigned char* const Xsb = Wsb + 2 * 32 * WLD * ESZ;                    // [4][32*XLDW]
+    __bf16* const Ws = reinterpret_cast<__bf16*>(Wsb);
+    __bf16* const Xs = reinterpret_cast<__bf16*>(Xsb);
+    float* const Ps = reinterpret_cast<float*>(Xsb + 4 * 32 * XLDW * ESZ);  // bias [N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
@@ -539,13 +628,13 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
 
     // two-deep register ring for the weight chunks (see the resident kernel); chunk nt uses set / buffer nt & 1
     u32x4 wreg[2][WLOADS];
-    const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+    const unsigned char* Wpb = reinterpret_cast<const unsigned char*>(p.W);
     auto load_chunk = [&](int set, int nt) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) wreg[set][i] = *reinterpret_cast<const u32x4*>(Wp + (long)(nt * 32 + row) * p.ldw + 8 * piece);
+            if ((32 * PIECES) % 256 == 0 || row < 32) wreg[set][i] = *reinterpret_cast<const u32x4*>(Wpb + (long)(nt * 32 + row) * p.ldw * ESZ + 16 * piece);
         }
     };
     auto store_chunk = [&](int set) {
@@ -553,9 +642,12 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / PIECES, piece = f % PIECES;
-            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Ws[set * 32 * WLD + row * WLD + 8 * piece]) = wreg[set][i];
+            if ((32 * PIECES) % 256 == 0 || row < 32) *reinterpret_cast<u32x4*>(&Wsb[(set * 32 * WLD + row * WLD) * ESZ + 16 * piece]) = wreg[set][i];
         }
     };
+    const int sc_w = F8 ? 127 - *p.w_exp : 0, sc_x = F8 ? 127 - p.x_exp : 0;
+    const float xscale = F8 ? exp2i(p.x_exp) : 1.f;
+    unsigned char* const xs8 = Xsb + wave * 32 * XLDW;
 
     unsigned long long t_start = 0, t_x = 0, t_it0 = 0;
     if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
@@ -564,14 +656,21 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     for (int i = tid; i < p.N; i += 256) Ps[i] = p.bias ? p.bias[i] : 0.f;
     store_chunk(0);
 
-    bf16x8 xf[KSL / 16];
+    bf16x8 xf[F8 ? 1 : KSL / 16];
+    i32x8 xf8[F8 ? KSL / 64 : 1];
 #pragma unroll
     for (int q = 0; q < KSL / XW; ++q) {
-        if (!(p.dbg & 8)) stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
+        if constexpr (F8) stage_x8<XW, XLDW, XB, 32>(p, xs8, tok0, last_tok, q * XW, lane, xscale);
+        else if (!(p.dbg & 8)) stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (F8) {
 #pragma unroll
-        for (int s = 0; s < XW / 16; ++s) xf[q * (XW / 16) + s] = *reinterpret_cast<const bf16x8*>(&xs[c * XLDW + 16 * s + 8 * h]);
+            for (int s = 0; s < XW / 64; ++s) xf8[q * (XW / 64) + s] = lds_frag32(xs8 + c * XLDW + 64 * s + 32 * h);
+        } else {
+#pragma unroll
+            for (int s = 0; s < XW / 16; ++s) xf[q * (XW / 16) + s] = *reinterpret_cast<const bf16x8*>(&xs[c * XLDW + 16 * s + 8 * h]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -634,6 +733,12 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if constexpr (F8) {
+            const unsigned char* wsb8 = Wsb + buf * 32 * WLD + arow * WLD + 32 * h;
+#pragma unroll
+            for (int s = 0; s < KSL / 64; ++s)
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(lds_frag32(wsb8 + 64 * s), xf8[s], acc, 0, 0, 0, sc_w, 0, sc_x);
+        } else {
         const __bf16* wsb = Ws + buf * 32 * WLD + arow * WLD + 8 * h;
 #pragma unroll
         for (int s4 = 0; s4 < KSL / 64; ++s4) {
@@ -644,6 +749,7 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
             }
+        }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -718,6 +824,34 @@ __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ 
     }
 }
 
+// e4m3 shadow of the 2-D weights (forward orientation [rows][cols]) with one power-of-two scale per tensor:
+// pass 1: amax[entry] = max |w| (the bit pattern of a non-negative float orders like an unsigned integer);
+// pass 2: w_exp[entry] = floor(log2(448 / amax)) (the largest power of two that keeps the tensor inside the e4m3 range),
+//         w8[2 * off + i] = e4m3(w[off + i] * 2^w_exp)   (byte offset 2 * off keeps every tensor 16-byte aligned)
+__global__ void shadow8_amax_k(const float* __restrict__ w, unsigned* __restrict__ amax, const ShadowEntry* __restrict__ tab) {
+    const ShadowEntry e = tab[blockIdx.y];
+    const long n = (long)e.rows * e.cols;
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[e.off + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax + blockIdx.y, __builtin_bit_cast(unsigned, m));
+}
+__global__ void shadow8_quant_k(const float* __restrict__ w, unsigned char* __restrict__ w8, const unsigned* __restrict__ amax,
+                                int* __restrict__ w_exp, const ShadowEntry* __restrict__ tab) {
+    const ShadowEntry e = tab[blockIdx.y];
+    const float am = __builtin_bit_cast(float, amax[blockIdx.y]);
+    int ex = am > 0.f ? ilogbf(448.f / am) : 0;
+    ex = max(-24, min(24, ex));
+    if (blockIdx.x == 0 && threadIdx.x == 0) w_exp[blockIdx.y] = ex;
+    const float sc = exp2i(ex);
+    const long n4 = ((long)e.rows * e.cols) / 4;          // slots are multiples of 8 elements
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + e.off + 4 * i);
+        *reinterpret_cast<unsigned*>(w8 + 2 * e.off + 4 * i) = cvt4_fp8(v[0], v[1], v[2], v[3], sc);
+    }
+}
+
 template <int NT_RES, int KSL, bool XB, int PRE>
 int launch_res(const TlinP& p, hipStream_t st) {
     constexpr size_t smem = (size_t)6 * 32 * (KSL + 8) * 2 + (size_t)3 * 32 * NT_RES * 4;
@@ -731,31 +865,32 @@ int launch_res(const TlinP& p, hipStream_t st) {
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int NT_RES, int KSL, bool XB, int PRE>
+template <int NT_RES, int KSL, bool XB, int PRE, bool F8 = false>
 int launch_res16(const TlinP& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(2 * 32 + 4 * 16) * (KSL + 8) * 2 + (size_t)3 * 32 * NT_RES * 4;
+    constexpr size_t smem = (size_t)(2 * 32 + 4 * 16) * (F8 ? KSL + 32 : (KSL + 8) * 2) + (size_t)3 * 32 * NT_RES * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_res16_kernel<NT_RES, KSL, XB, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_res16_kernel<NT_RES, KSL, XB, PRE, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const long blocks = (p.M + 63) / 64;
-    launch_timed(tlin_res16_kernel<NT_RES, KSL, XB, PRE>, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    launch_timed(tlin_res16_kernel<NT_RES, KSL, XB, PRE, F8>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 constexpr size_t STREAM_SMEM_MAX = 160 * 1024;
-template <int KSL, bool XB, bool YB, int EPI>
+template <int KSL, bool XB, bool YB, int EPI, bool F8 = false>
 int launch_str(const TlinP& p, hipStream_t st) {
     constexpr int XW = KSL < 128 ? KSL : 128;
-    const size_t smem = (size_t)2 * 32 * (KSL + 8) * 2 + (size_t)4 * 32 * (XW + 8) * 2 + (size_t)p.N * 4;
+    const size_t smem = F8 ? (size_t)2 * 32 * (KSL + 32) + (size_t)4 * 32 * (XW + 32) + (size_t)p.N * 4
+                           : (size_t)2 * 32 * (KSL + 8) * 2 + (size_t)4 * 32 * (XW + 8) * 2 + (size_t)p.N * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_str_kernel<KSL, XB, YB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STREAM_SMEM_MAX));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_str_kernel<KSL, XB, YB, EPI, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STREAM_SMEM_MAX));
         attr_set = true;
     }
     const long blocks = (p.M + 127) / 128;
-    launch_timed(tlin_str_kernel<KSL, XB, YB, EPI>, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    launch_timed(tlin_str_kernel<KSL, XB, YB, EPI, F8>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -765,6 +900,14 @@ int launch_str_t(const TlinP& p, hipStream_t st) {
     return p.y_bf16 ? launch_str<KSL, false, true, EPI>(p, st) : launch_str<KSL, false, false, EPI>(p, st);
 }
 // the specialised epilogues exist for the production width (K = 256); other widths take the run-time one
+// fp8 operands: the forward Linears of the production width (see tlin_fp8_supported)
+inline int GG_FAIL_FP8() { set_error("tlin: fp8 instantiation missing"); return -2; }
+int launch_fp8(const TlinP& p, hipStream_t st) {
+    if (p.ln_g) return launch_res16<8, 256, true, PRE_RES, true>(p, st);          // out-proj / FFN2 + residual + LayerNorm
+    if (p.x_bf16) return GG_FAIL_FP8();
+    if (p.drop.p > 0.f) return launch_str<256, false, true, EPI_DROP, true>(p, st);   // FFN1 (+ ReLU + dropout)
+    return launch_str<256, false, true, EPI_BIAS, true>(p, st);                       // QKV, FFN1 without dropout
+}
 int launch_str_256(const TlinP& p, hipStream_t st) {
     if (p.accumulate || (p.mask_ref && p.drop.p > 0.f)) return launch_str_t<256, EPI_ANY>(p, st);
     if (p.mask_ref) return launch_str_t<256, EPI_MASK>(p, st);
@@ -816,6 +959,7 @@ bool tlin_supported(const TlinP& p) {
 // which kernel tlin() launches for p (profiling classes follow the kernels' own names): 0 tlin_str_kernel, 1 tlin_res_kernel
 // (32-token waves), 2 tlin_res16_kernel<..., PRE_RES> (+ residual + LayerNorm), 3 <..., PRE_ACC> (+=), 4 other res16 modes
 int tlin_kernel_class(const TlinP& p) {
+    if (p.fp8) return p.ln_g ? 29 : (p.drop.p > 0.f ? 31 : 30);       // stream-class slots 13 .. 15 (see engine.hip try_tlin)
     if (!needs_resident(p)) {
         if (p.K != 256) return 0;
         // 16 + the <XB, YB, EPI> instantiation launch_str_256 picks: bit 0 XB, bit 1 YB, bits 2..3 EPI
@@ -834,11 +978,24 @@ int tlin_kernel_class(const TlinP& p) {
 
 void tlin_time_next(hipEvent_t begin, hipEvent_t end) { g_ev0 = begin; g_ev1 = end; }
 
+// fp8 operand path: the four forward Linears of an encoder layer at the production width - stream (QKV, FFN1: fp32 X,
+// bf16 Y, K = 256, bias (+ReLU) (+dropout)) and resident + residual + LayerNorm (out-proj, FFN2: bf16 X, N = 256, K % 256 == 0)
+bool tlin_fp8_supported(const TlinP& p) {
+    if (!p.fp8 || !p.w_exp || !tlin_supported(p)) return false;
+    if (p.film_g || p.mask_ref || p.accumulate || p.y_row_group) return false;
+    if (p.ln_g) return p.N == 256 && p.K % 256 == 0 && p.x_bf16 && p.res && !p.act_relu && !p.y_bf16;
+    return p.K == 256 && !p.x_bf16 && p.y_bf16 && !p.res;
+}
+
 int tlin(const TlinP& p_in, hipStream_t st) {
     GG_REQUIRE(tlin_supported(p_in), "tlin: unsupported shape / alignment");
     static const int dbg = getenv("GG_TLIN_DBG") ? atoi(getenv("GG_TLIN_DBG")) : 0;
     TlinP p = p_in;
     p.dbg = dbg;
+    if (p.fp8) {
+        GG_REQUIRE(tlin_fp8_supported(p), "tlin: shape has no fp8 instantiation");
+        return launch_fp8(p, st);
+    }
     if (!needs_resident(p)) {
         if (p.K == 256) return launch_str_256(p, st);
         if (p.K == 128) return launch_str_t<128, EPI_ANY>(p, st);
@@ -847,6 +1004,15 @@ int tlin(const TlinP& p_in, hipStream_t st) {
     if (p.N == 256) return launch_res_256(p, st);
     if (p.N == 128) return launch_res_t<4, 128, PRE_ANY>(p, st);
     return launch_res_t<2, 64, PRE_ANY>(p, st);
+}
+
+int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {
+    if (n_entries <= 0) return 0;
+    GG_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * n_entries, st));
+    shadow8_amax_k<<<dim3(64, n_entries), 256, 0, st>>>(w, amax, tab_dev);
+    shadow8_quant_k<<<dim3(64, n_entries), 256, 0, st>>>(w, reinterpret_cast<unsigned char*>(w8), amax, w_exp, tab_dev);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {

@@ -34,6 +34,8 @@ extern "C" {
 /* arithmetic of the GEMM-shaped products (everything else is fp32 in both modes) */
 #define GG_PREC_F32 0  /* fp32-input MFMA: exact fp32, the parity mode (<= 1e-3 vs the reference) */
 #define GG_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate: the throughput mode               */
+#define GG_PREC_FP8 2  /* GG_PREC_BF16 with OCP e4m3 operands (block-scaled v_mfma_scale_f32_*_f8f6f4, fp32 accumulate,    */
+                       /* per-tensor power-of-two scales) in the forward Linears of the encoder layers: BASELINE configs[4] */
 
 #define GG_OPT_RMSPROP 0 /* torch.optim.RMSprop(lr)                       R:324 */
 #define GG_OPT_ADAM 1    /* torch.optim.Adam(lr, betas=(.9,.99))          R:327 */
