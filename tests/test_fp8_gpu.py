@@ -1,0 +1,149 @@
+"""fp8 mode (GG_PREC_FP8: OCP e4m3 operands on the block-scaled matrix instructions in the forward Linears of the encoder
+layers, everything else as in bf16 mode; BASELINE configs[4] asks for it).
+
+(1) EXACTNESS of the operand path: every fp8 Linear must equal, to the rounding of its bf16 / fp32 output, the product of
+    the e4m3-quantised operands computed in float64 on the host - x8 = e4m3(x * 2^3) / 2^3, w8 = e4m3(w * 2^e) / 2^e with
+    e = floor(log2(448 / max|w|)) - which pins the fragment maps of v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4, the scale
+    operands and the quantisation itself (a wrong lane map gives O(1) errors).
+(2) QUANTITATIVE ERROR of the mode against the fp32 oracle (stage activations, losses, gradients), with bounds.
+(3) The per-GPU shape of configs[4] runs in this mode and stays finite."""
+import numpy as np
+import pytest
+import torch
+
+from gemm_gan_amd import _lib as L
+from gpu_util import dev, diag, engine_from_cfg, load_oracle_state
+from oracle.torch_oracle import Trainer, img_config, synthetic_batch
+from test_bf16_parity_gpu import Gate, significant
+from test_engine_oracle_gpu import CASES, _cos, setup
+
+pytestmark = pytest.mark.gpu
+X_EXP = 3
+
+
+def e4m3(t):
+    """Round to OCP e4m3 (saturating at +-448) and back, on the host."""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float64)
+
+
+def q_act(x):
+    return e4m3(x.double() * 2.0 ** X_EXP) / 2.0 ** X_EXP
+
+
+def q_weight(w):
+    am = float(w.abs().max())
+    e = int(np.floor(np.log2(448.0 / am))) if am > 0 else 0
+    e = max(-24, min(24, e))
+    return e4m3(w.double() * 2.0 ** e) / 2.0 ** e
+
+
+def layernorm(r, g, b):
+    mu = r.mean(-1, keepdim=True)
+    var = ((r - mu) ** 2).mean(-1, keepdim=True)
+    return (r - mu) / torch.sqrt(var + 1e-5) * g + b
+
+
+def bf16_round(t):
+    return t.float().to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+def test_fp8_linears_equal_the_product_of_the_quantised_operands(case):
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    eng.set_precision("fp8")
+    B, P = x.shape[0], patches.shape[1]
+    S, E, F = P + 1, cfg.embedding_dims, 2 * cfg.embedding_dims
+    xg, tg, tpg, pg, ppg = dev(x, text, text_pad, patches, patch_pad)
+    eng.forward(L.ROLE_CRITIC, xg, pg, ppg, tg, tpg, train=False)
+    sd = {k: v.detach().double() for k, v in tr.disc.state_dict().items()}
+    buf = lambda name, *shape: eng.debug_buffer(name).view(*shape).double().cpu()
+    diag(f"== fp8 Linears vs host emulation of the quantised product ({case})")
+    worst = 0.0
+    x_in = buf("D.x0", B * S, E)
+    for l in range(2):
+        pre = f"patches_transformer.layers.{l}."
+        qkv, ctx = buf(f"D.L{l}.qkv", B * S, 3 * E), buf(f"D.L{l}.ctx", B * S, E)
+        x1, h, x2 = buf(f"D.L{l}.x1", B * S, E), buf(f"D.L{l}.h", B * S, F), buf(f"D.L{l}.x2", B * S, E)
+        want = {
+            "qkv": bf16_round(q_act(x_in) @ q_weight(sd[pre + "self_attn.in_proj_weight"]).T + sd[pre + "self_attn.in_proj_bias"]),
+            "x1": layernorm(x_in + q_act(ctx) @ q_weight(sd[pre + "self_attn.out_proj.weight"]).T + sd[pre + "self_attn.out_proj.bias"],
+                            sd[pre + "norm1.weight"], sd[pre + "norm1.bias"]),
+            "h": bf16_round(torch.relu(q_act(x1) @ q_weight(sd[pre + "linear1.weight"]).T + sd[pre + "linear1.bias"])),
+            "x2": layernorm(x1 + q_act(h) @ q_weight(sd[pre + "linear2.weight"]).T + sd[pre + "linear2.bias"],
+                            sd[pre + "norm2.weight"], sd[pre + "norm2.bias"]),
+        }
+        for name, got in (("qkv", qkv), ("x1", x1), ("h", h), ("x2", x2)):
+            err = float((got - want[name]).abs().max() / want[name].abs().max())
+            worst = max(worst, err)
+            diag(f"   layer {l} {name:4s} max-norm error vs emulation {err:.3e}")
+            # bf16-stored outputs carry one bf16 rounding (2^-9 relative per element); fp32 ones only accumulation order
+            assert err <= (6e-3 if name in ("qkv", "h") else 2e-4), (l, name, err)
+        x_in = x2
+    diag(f"   worst {worst:.3e}")
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+def test_fp8_mode_error_against_the_fp32_oracle(case):
+    """e4m3 has 3 mantissa bits: 2^-4 relative rounding per operand element, ~3 % of a dot product's typical magnitude.
+    Measured (gpurun_out/parity_diag.txt): encoder output 3e-2 rel-L2, critic score 6e-3, losses 2..5e-3, gradient cosine 0.994; bounds 5e-2 / 3e-2 / 2e-2 / 0.98
+    (gradients additionally carry the ReLU gate flips described in tests/test_bf16_parity_gpu.py)."""
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    eng.set_precision("fp8")
+    B, P, T = x.shape[0], patches.shape[1], text.shape[1]
+    S, E = P + 1, cfg.embedding_dims
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    alpha = torch.rand(B, 1, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    xg, tg, tpg, pg, ppg, zg, ag = dev(x, text, text_pad, patches, patch_pad, z, alpha)
+    gt = Gate(f"fp8 mode vs fp32 oracle {case}")
+    taps = {}
+    with torch.no_grad():
+        tr.disc.train()
+        ref_out = tr.disc(x, *cond, taps=taps)
+    out = eng.forward(L.ROLE_CRITIC, xg, pg, ppg, tg, tpg, train=True)
+    gt.check("act", "encoder output", eng.debug_buffer("D.L1.x2").view(B, S, E), taps["enc"], 5e-2)
+    gt.check("act", "conditioning vector", eng.debug_buffer("D.c").view(B, E), taps["cond"], 5e-2)
+    gt.check("act", "critic score", out, ref_out, 3e-2)
+    r = tr.critic_iteration(x, z, alpha, cond, apply=False)
+    eng.critic_backward(xg, zg, ag, pg, ppg, tg, tpg)
+    l = eng.losses.tolist()
+    gt.check("act", "generated genes", eng.debug_buffer("X2").view(2 * B, -1)[:B], r["x_fake"], 3e-2)
+    gt.check("loss", "d_real, d_fake", np.array(l[:2]), np.array([r["d_real"].item(), r["d_fake"].item()]), 2e-2)
+    grads = eng.state(L.ROLE_CRITIC, "g")
+    fa, fb = [], []
+    for n, ref in r["grads"].items():
+        if significant(ref) and not n.endswith("in_proj_bias"):
+            fa.append(grads[n].reshape(-1).cpu())
+            fb.append(ref.reshape(-1))
+    cs = _cos(torch.cat(fa), torch.cat(fb))
+    diag(f"   flat critic gradient cosine vs fp32 oracle: {cs:.5f}")
+    assert torch.isfinite(torch.cat(fa)).all() and cs >= 0.98, cs
+    gt.done()
+
+
+def test_fp8_mode_at_the_cfg5_rank_shape():
+    cfg = img_config(n_genes=18000, dropout=0.1)
+    B, P, T = 128, 1024, 1
+    torch.manual_seed(3)
+    tr = Trainer(cfg)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    eng.set_precision("fp8")
+    load_oracle_state(eng, tr)
+    x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=9, pad_patches=True))
+    g = torch.Generator().manual_seed(1)
+    z_all = torch.randn(3, B, cfg.latent_dims, generator=g).cuda()
+    alpha_all = torch.rand(2, B, generator=g).cuda()
+    b16 = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    b16.set_precision("bf16")
+    load_oracle_state(b16, tr)
+    a = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
+    b = b16.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
+    err = float((a - b).norm() / b.norm())
+    diag(f"== fp8 vs bf16 critic score at the cfg5 per-rank shape: rel-L2 {err:.3e}")
+    assert torch.isfinite(a).all() and err <= 0.15, err
+    del b16
+    eng.train_step(x, patches, patch_pad, text, text_pad, z_all, alpha_all)
+    assert torch.isfinite(eng.losses).all()
+    for role in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+        assert torch.isfinite(eng.flat[role]["w"]).all() and torch.isfinite(eng.flat[role]["g"]).all()
