@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
     constexpr int N = 32 * NT_RES;
     constexpr int NF = 2 * NT_RES;                     // 16-feature tiles
     constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
-    constexpr int WLD = F8 ? KSL + 32 : KSL + 8;       // elements per LDS row (weights and activations)
+    constexpr int WLD = F8 ? KSL + 16 : KSL + 8;       // elements per LDS row (weights and activations): 4 banks per row step
     constexpr int PIECES = KSL * ESZ / 16;             // 16-byte pieces per weight row
     constexpr int WLOADS = (32 * PIECES + 255) / 256;
     constexpr int KS32 = F8 ? KSL / 128 : KSL / 32;    // MFMA steps per K slice (fragments held)
@@ -509,6 +509,9 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
                     for (int s = 0; s < KS32; ++s)
                         acc[2 * nt + ft] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(lds_frag32(wsb8 + 128 * s), xf8[s], acc[2 * nt + ft],
                                                                                              0, 0, 0, sc_w, 0, sc_x);
+                    // keep this chunk's fragment reads and products together: left alone, the compiler sinks the products
+                    // of ALL chunks below the chunk loop and keeps 256 registers of fragments alive (spilled) until then
+                    asm volatile("" : "+v"(acc[2 * nt + ft]));
                     continue;
                 }
                 const __bf16* wsb = Ws + buf * 32 * WLD + (16 * ft + c) * WLD + 8 * q;
@@ -528,6 +531,8 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
                         acc[2 * nt + ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf[s], acc[2 * nt + ft], 0, 0, 0);
                     }
                 }
+                // the tile's products are materialised here (see the fp8 branch): -16 B of spills per lane, -8 % kernel time
+                asm volatile("" : "+v"(acc[2 * nt + ft]));
             }
             if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
             __syncthreads();
@@ -867,7 +872,7 @@ int launch_res(const TlinP& p, hipStream_t st) {
 }
 template <int NT_RES, int KSL, bool XB, int PRE, bool F8 = false>
 int launch_res16(const TlinP& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(2 * 32 + 4 * 16) * (F8 ? KSL + 32 : (KSL + 8) * 2) + (size_t)3 * 32 * NT_RES * 4;
+    constexpr size_t smem = (size_t)(2 * 32 + 4 * 16) * (F8 ? KSL + 16 : (KSL + 8) * 2) + (size_t)3 * 32 * NT_RES * 4;
     static bool attr_set = false;
     if (!attr_set) {
         GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin_res16_kernel<NT_RES, KSL, XB, PRE, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
