@@ -191,7 +191,7 @@ struct gg_engine {
     size_t prof_next = 0;
     struct ProfAgg { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
     std::vector<ProfAgg> prof_agg;
-    int str_cls[16] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
+    int str_cls[32] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
 };
@@ -582,8 +582,12 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
-            if (kc == 29) snprintf(nm, sizeof nm, "tlin_res16_kernel<8,256,true,1,true>");
-            else if (kc >= 30) snprintf(nm, sizeof nm, "tlin_str_kernel<256,false,true,%d,true>", kc - 30);
+            static const char* extra[10] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
+                                            "wst_ln_kernel<8,2,16,false,2>", "wst_ln_kernel<8,2,16,true,3>", "wst_ln_kernel<4,2,16,true,2>",
+                                            "wst_ln_kernel<8,1,48,true,1>",
+                                            "tlin_res16_kernel<8,256,true,1,true>", "tlin_str_kernel<256,false,true,0,true>",
+                                            "tlin_str_kernel<256,false,true,1,true>"};
+            if (kc >= 32) snprintf(nm, sizeof nm, "%s", extra[kc - 32]);
             else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
             e->str_cls_name[id - 18] = nm;

@@ -162,7 +162,13 @@ struct TlinP {
     unsigned long long* stamps = nullptr;           // tools/tlin_probe: 4 s_memtime stamps per workgroup (wave 0)
 };
 bool tlin_supported(const TlinP& p);
-bool tlin_fp8_supported(const TlinP& p);            // p.fp8 set and one of the fp8 instantiations takes the shape
+bool tlin_fp8_supported(const TlinP& p);
+// weight-stationary variant of the Linear + dropout + residual + LayerNorm calls (wst.hip): N = 256, K in {256, 512}, bf16 X.
+// tlin() routes such calls there (GG_NO_WST=1 in the environment keeps the token-on-lane kernel, for A/B runs)
+bool wst_ln_supported(const TlinP& p);
+int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int wst_kind(const TlinP& p);          // 0: none; 1 += (N 256, K 512); 2 relu/dropout -> bf16 (N 512, K 256, fp32 X); 3 gated -> bf16
+int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);            // p.fp8 set and one of the fp8 instantiations takes the shape
 int tlin(const TlinP& p, hipStream_t st);
 void tlin_time_next(hipEvent_t begin, hipEvent_t end);     // the next tlin() launch stamps these at the kernel's own begin / end
 // 0 stream (K != 256), 1 resident 32-token, 2/3/4 resident 16-token (+res+LN / += / other),

@@ -603,8 +603,14 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
 // ---- stream: K <= 256 register-resident, N streamed 32 features at a time ----------------------------------------
 // EPI: 0 bias (+ReLU), 1 bias (+ReLU) + dropout, 2 bias + sign mask of a reference tensor, 3 decided at run time
 enum { EPI_BIAS = 0, EPI_DROP = 1, EPI_MASK = 2, EPI_ANY = 3 };
+#ifndef GG_STR_CB
+#define GG_STR_CB 4
+#endif
+#ifndef GG_STR_OCC
+#define GG_STR_OCC 2
+#endif
 template <int KSL, bool XB, bool YB, int EPI, bool F8 = false>
-__global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
+__global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p) {
     constexpr int XW = KSL < 128 ? KSL : 128;          // staging window (bounds LDS so two workgroups fit a CU)
     constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
     constexpr int XLDW = F8 ? XW + 32 : XW + 8;
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
     // bf16 results are held back for CB = 4 feature chunks and written together: per token 4 x 64 contiguous bytes in
     // one burst (full 128-byte lines reach L2 / HBM at once).  Written chunk by chunk, a row's 64-byte pieces arrive
     // microseconds apart and the write stream measured 3.5 TB/s against 5.7 for the burst shape (tools/bw_probe).
-    constexpr int CB = 4;
+    constexpr int CB = GG_STR_CB;
     unsigned held[CB][8];
     auto tile = [&](auto slot_tag, int nt) {
         constexpr int slot = decltype(slot_tag)::value;
@@ -807,8 +813,10 @@ __global__ __launch_bounds__(256, 2) void tlin_str_kernel(const TlinP p) {
         tile(std::integral_constant<int, 0>{}, nt);
         if (nt + 1 < ntiles) tile(std::integral_constant<int, 1>{}, nt + 1);
         if (p.stamps && nt == 0) t_it0 = __builtin_amdgcn_s_memtime();
-        if (nt + 2 < ntiles) tile(std::integral_constant<int, 2>{}, nt + 2);
-        if (nt + 3 < ntiles) tile(std::integral_constant<int, 3>{}, nt + 3);
+        if constexpr (CB > 2) {
+            if (nt + 2 < ntiles) tile(std::integral_constant<int, 2>{}, nt + 2);
+            if (nt + 3 < ntiles) tile(std::integral_constant<int, 3>{}, nt + 3);
+        }
     }
     if (p.stamps && tid == 0) {
         unsigned long long* o = p.stamps + 4 * (long)blockIdx.x;
@@ -963,8 +971,16 @@ bool tlin_supported(const TlinP& p) {
 
 // which kernel tlin() launches for p (profiling classes follow the kernels' own names): 0 tlin_str_kernel, 1 tlin_res_kernel
 // (32-token waves), 2 tlin_res16_kernel<..., PRE_RES> (+ residual + LayerNorm), 3 <..., PRE_ACC> (+=), 4 other res16 modes
+bool wst_routed(const TlinP& p) {
+    static const bool off = getenv("GG_NO_WST") != nullptr;
+    static const bool off2 = getenv("GG_NO_WST2") != nullptr;
+    if (off || p.fp8) return false;
+    return wst_ln_supported(p) || (!off2 && wst_kind(p) != 0);
+}
+// classes >= 32: kernels outside the tlin_str_kernel<256, XB, YB, EPI> family (engine.hip try_tlin names them)
 int tlin_kernel_class(const TlinP& p) {
-    if (p.fp8) return p.ln_g ? 29 : (p.drop.p > 0.f ? 31 : 30);       // stream-class slots 13 .. 15 (see engine.hip try_tlin)
+    if (wst_routed(p)) return wst_ln_supported(p) ? (p.K == 256 ? 32 : 33) : 33 + wst_kind(p);      // 32 .. 38
+    if (p.fp8) return p.ln_g ? 39 : (p.drop.p > 0.f ? 41 : 40);
     if (!needs_resident(p)) {
         if (p.K != 256) return 0;
         // 16 + the <XB, YB, EPI> instantiation launch_str_256 picks: bit 0 XB, bit 1 YB, bits 2..3 EPI
@@ -982,6 +998,7 @@ int tlin_kernel_class(const TlinP& p) {
 }
 
 void tlin_time_next(hipEvent_t begin, hipEvent_t end) { g_ev0 = begin; g_ev1 = end; }
+bool wst_routed(const TlinP& p);
 
 // fp8 operand path: the four forward Linears of an encoder layer at the production width - stream (QKV, FFN1: fp32 X,
 // bf16 Y, K = 256, bias (+ReLU) (+dropout)) and resident + residual + LayerNorm (out-proj, FFN2: bf16 X, N = 256, K % 256 == 0)
@@ -1000,6 +1017,11 @@ int tlin(const TlinP& p_in, hipStream_t st) {
     if (p.fp8) {
         GG_REQUIRE(tlin_fp8_supported(p), "tlin: shape has no fp8 instantiation");
         return launch_fp8(p, st);
+    }
+    if (wst_routed(p)) {
+        hipEvent_t a = g_ev0, b = g_ev1;
+        g_ev0 = g_ev1 = nullptr;
+        return wst_ln_supported(p) ? wst_ln(p, st, a, b) : wst_other(p, st, a, b);
     }
     if (!needs_resident(p)) {
         if (p.K == 256) return launch_str_256(p, st);

@@ -1,0 +1,350 @@
+// Weight-stationary Linear + dropout + residual + LayerNorm for the encoder width (N = 256 output features).
+//
+//   r = res + drop(X W^T + bias) ;  y = LayerNorm(r) * gamma + beta         (out-proj / FFN2 of an encoder layer, forward)
+//
+// The token-on-lane kernels of tlin.hip keep the ACTIVATIONS of a wave's tokens in registers and stream the weights through
+// LDS: 128 KB (K = 256) or 256 KB (K = 512) of weights per 64 tokens, one barrier and one L2 round trip per 32-feature chunk
+// - the waves spend 60 % of their time waiting for those chunks (profiles/r02_pmc_mfma.json) and the kernel sits at 0.4 of
+// the HBM roofline although it moves only activations through HBM.  Here the roles are swapped:
+//   * a PERSISTENT workgroup loads its share of W once, as MFMA A fragments that stay in registers for the whole launch
+//     (wave w owns output features [N/NW * w, N/NW * (w+1)): RT row tiles of 32, all K);
+//   * token tiles of 32 rows stream through a double-buffered LDS image of X (the only LDS traffic besides two floats per
+//     token and wave), every wave multiplies the whole tile against its resident rows: RT * K/16 back-to-back MFMAs;
+//   * accumulators have features in registers and tokens on lanes (rows fed in the permuted order of tlin.hip, so a lane
+//     owns 16 consecutive features: 64-byte runs for residual loads and stores); LayerNorm needs all 256 features of a
+//     token, which live in NW waves: each wave contributes (sum, sum of squares) of its slice through LDS.
+// K = 256: 4 waves x 2 row tiles (128 weight registers per lane), two workgroups per CU; K = 512: 8 waves x 1 row tile.
+// Same arithmetic, same dropout stream (element index = token * drop_ld + feature) as tlin_res16_kernel.
+//
+// The same structure with other epilogues (EPI): ACC  y += X W^T (fp32; the data-gradient Linears dx1 += dh W1, N = 256,
+// K = 512), ACT  y = drop(relu(X W^T + b)) -> bf16 (FFN1, N = 512, K = 256, fp32 X converted while staging), MASK
+// y = (X W^T) * [ref > 0] * scale -> bf16 (dh = (dres W2) gated by the stored hidden activations).
+#include "kernels.h"
+#include "drop_rng.h"
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace gg {
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr float LN_EPS = 1e-5f;
+constexpr int TT = 32;                                  // tokens per tile
+
+__device__ __forceinline__ int a_row_of_lane(int r) { return 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3); }
+
+enum { EPI_LN = 0, EPI_ACC = 1, EPI_ACT = 2, EPI_MASK = 3 };
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN>
+__global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
+    constexpr int K = 16 * KS, N = 32 * NW * RT, NTH = 64 * NW;
+    constexpr int XLD = K + 8;                          // bf16 per LDS row: 4 banks per row step, conflict-free 16-byte reads
+    constexpr int PPR = XB ? K / 8 : K / 4;             // 16-byte pieces per row of X as stored in memory
+    constexpr int XP = TT * PPR / NTH;                  // pieces per thread and tile
+    static_assert(TT * PPR % NTH == 0, "tile staging must divide evenly");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const Xs = reinterpret_cast<__bf16*>(smem_raw);                        // [2][TT * XLD]
+    float* const Red = reinterpret_cast<float*>(Xs + 2 * TT * XLD);                // [2][NW][TT][2]  (sum, sum of squares)
+    float* const Ps = Red + 2 * NW * TT * 2;                                       // bias | gamma | beta  [3][N]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int f0 = 32 * RT * wave;                      // first output feature of this wave
+    const long ntiles = (p.M + TT - 1) / TT;
+    const int last_tok = (int)p.M - 1;
+
+    // resident weights: A fragment of k-step s for row tile rt = W[f0 + 32 rt + a_row_of_lane(c)][16 s + 8 h .. + 7]
+    bf16x8 wA[RT][KS];
+    {
+        const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const __bf16* wr = Wp + (long)(f0 + 32 * rt + a_row_of_lane(c)) * p.ldw + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wA[rt][s] = *reinterpret_cast<const bf16x8*>(wr + 16 * s);
+        }
+    }
+    for (int i = tid; i < N; i += NTH) {
+        Ps[i] = p.bias ? p.bias[i] : 0.f;
+        if constexpr (EPI == EPI_LN) {
+            Ps[N + i] = p.ln_g[i];
+            Ps[2 * N + i] = p.ln_b[i];
+        }
+    }
+
+    // staging of one X tile: thread -> XP pieces (row = f / PPR, piece = f % PPR), rows past the end clamped
+    const unsigned char* Xp = reinterpret_cast<const unsigned char*>(p.X);
+    u32x4 xr[XP];
+    auto load_x = [&](long tile) {
+        const int tok0 = (int)(tile * TT);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int f = tid + NTH * i, row = f / PPR, pc = f % PPR;
+            xr[i] = *reinterpret_cast<const u32x4*>(Xp + (long)min(tok0 + row, last_tok) * p.ldx * (XB ? 2 : 4) + 16 * pc);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int f = tid + NTH * i, row = f / PPR, pc = f % PPR;
+            if constexpr (XB) {
+                *reinterpret_cast<u32x4*>(&Xs[buf * TT * XLD + row * XLD + 8 * pc]) = xr[i];
+            } else {        // fp32 in memory, bf16 in LDS
+                const f32x4 v = __builtin_bit_cast(f32x4, xr[i]);
+                *reinterpret_cast<u32x2*>(&Xs[buf * TT * XLD + row * XLD + 4 * pc]) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        }
+    };
+
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    load_x(tile);
+    store_x(0);
+    if (tile + gridDim.x < ntiles) load_x(tile + gridDim.x);
+    const float ksd = p.drop.p > 0.f ? 1.f / (1.f - p.drop.p) : 1.f;
+    const bool drop_on = p.drop.p > 0.f;
+
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int tok = (int)(tile * TT) + c;
+        const bool valid = tok <= last_tok;
+        const int tokc = valid ? tok : last_tok;        // clamped lanes recompute the last row; their stores are predicated off
+        const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
+        __syncthreads();                                // X(tile) is in Xs[buf]; Red[buf] of two tiles ago has been consumed
+        // epilogue operands of this tile (residual rows / previous output / gate reference): requested before the products
+        f32x4 res[EPI == EPI_LN || EPI == EPI_ACC ? RT : 1][4];
+        u32x4 mref[EPI == EPI_MASK ? RT : 1][2];
+        if constexpr (EPI == EPI_LN) {
+            const float* resp = p.res + (long)(tokc % (int)p.res_rows) * p.ldres + f0 + 16 * h;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(resp + 32 * rt + 4 * g);
+        }
+        if constexpr (EPI == EPI_ACC) {
+            const float* yo = reinterpret_cast<const float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(yo + 32 * rt + 4 * g);
+        }
+        if constexpr (EPI == EPI_MASK) {
+            const __bf16* mr = reinterpret_cast<const __bf16*>(p.mask_ref) + (long)tokc * p.ldref + f0 + 16 * h;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                mref[rt][0] = *reinterpret_cast<const u32x4*>(mr + 32 * rt);
+                mref[rt][1] = *reinterpret_cast<const u32x4*>(mr + 32 * rt + 8);
+            }
+        }
+        f32x16 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+        const __bf16* xb = Xs + buf * TT * XLD + c * XLD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[rt][s], xf, acc[rt], 0, 0, 0);
+        }
+        // the next tile's rows (already in registers) go to the other buffer, the tile after that is requested
+        if (tile + gridDim.x < ntiles) {
+            store_x(buf ^ 1);
+            if (tile + 2L * gridDim.x < ntiles) load_x(tile + 2L * gridDim.x);
+        }
+        if constexpr (EPI != EPI_LN) {
+            // ---- plain epilogues: no cross-wave step, one barrier per tile ------------------------------------------
+            const uint64_t dbase2 = (uint64_t)tokc * p.drop_ld + f0 + 16 * h;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                unsigned packed[8];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[f0 + 32 * rt + 16 * h + 4 * g]);
+                    f32x4 v = {acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]};
+                    v += bb;
+                    if constexpr (EPI == EPI_ACC) {
+                        v += res[rt][g];
+                        if (valid) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h + 32 * rt + 4 * g) = v;
+                    }
+                    if constexpr (EPI == EPI_ACT) {
+                        if (p.act_relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        if (drop_on) {
+                            float f[4];
+                            drop_factor4(p.drop, dbase2 + 32 * rt + 4 * g, ksd, f);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= f[j];
+                        }
+                    }
+                    if constexpr (EPI == EPI_MASK) {
+                        const unsigned w0 = mref[rt][g >> 1][2 * (g & 1)], w1 = mref[rt][g >> 1][2 * (g & 1) + 1];
+                        const float m[4] = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                                            __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] * p.mask_scale : 0.f;
+                    }
+                    packed[2 * g] = pack2(v[0], v[1]);
+                    packed[2 * g + 1] = pack2(v[2], v[3]);
+                }
+                if constexpr (EPI == EPI_ACT || EPI == EPI_MASK) {
+                    if (valid) {
+                        __bf16* yo = reinterpret_cast<__bf16*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h + 32 * rt;
+                        *reinterpret_cast<u32x4*>(yo) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+                        *reinterpret_cast<u32x4*>(yo + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
+                    }
+                }
+            }
+        } else {
+        // ---- epilogue 1: bias, dropout, residual; r stored; this wave's share of the row sums ------------------------
+        float s1 = 0.f, s2 = 0.f;
+        float* const yb = reinterpret_cast<float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h;
+        const uint64_t dbase = (uint64_t)tokc * p.drop_ld + f0 + 16 * h;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[f0 + 32 * rt + 16 * h + 4 * g]);
+                f32x4 v = {acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]};
+                v += bb;
+                if (drop_on) {
+                    float f[4];
+                    drop_factor4(p.drop, dbase + 32 * rt + 4 * g, ksd, f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= f[j];
+                }
+                v += res[rt][g];
+                if (valid && keep_y) *reinterpret_cast<f32x4*>(yb + 32 * rt + 4 * g) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[rt][4 * g + j] = v[j];
+                    s1 += v[j];
+                    s2 += v[j] * v[j];
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* const red = Red + buf * NW * TT * 2;
+        if (h == 0) *reinterpret_cast<float2*>(&red[(wave * TT + c) * 2]) = float2{s1, s2};
+        __syncthreads();
+        // ---- epilogue 2: LayerNorm over the N features of the token (NW partial sums), y stored ------------------------
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float2 v = *reinterpret_cast<const float2*>(&red[(w * TT + c) * 2]);
+            t1 += v.x;
+            t2 += v.y;
+        }
+        const float mean = t1 * (1.f / N);
+        const float var = fmaxf(t2 * (1.f / N) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + LN_EPS);
+        float* const lb = p.ln_y + (long)tokc * p.ldy + f0 + 16 * h;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = f0 + 32 * rt + 16 * h + 4 * g;
+                const f32x4 gg_ = *reinterpret_cast<const f32x4*>(&Ps[N + n]);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[2 * N + n]);
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (acc[rt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
+                if (valid) *reinterpret_cast<f32x4*>(lb + 32 * rt + 4 * g) = y;
+            }
+        }
+        if (wave == 0 && h == 0 && valid && keep_y) {
+            p.ln_stats[2 * (long)tok] = mean;
+            p.ln_stats[2 * (long)tok + 1] = rstd;
+        }
+        }       // EPI_LN
+    }
+}
+
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN>
+int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int K = 16 * KS, N = 32 * NW * RT;
+    constexpr size_t smem = (size_t)2 * TT * (K + 8) * 2 + (size_t)2 * NW * TT * 2 * 4 + (size_t)3 * N * 4;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int dev = 0;
+        GG_CHECK_HIP(hipGetDevice(&dev));
+        GG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    const long ntiles = (p.M + TT - 1) / TT;
+    const long slots = (long)n_cu * (NW == 4 ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8
+    const unsigned grid = (unsigned)std::min<long>(ntiles, slots);
+    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
+    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI>), dim3(grid), dim3(64 * NW), smem, st, p);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+}  // namespace
+
+// out-proj / FFN2 of the production width, forward: bf16 X, fp32 residual + LayerNorm outputs
+bool wst_ln_supported(const TlinP& p) {
+    if (!p.ln_g || !p.ln_b || !p.ln_y || !p.ln_stats || !p.res || !p.x_bf16 || p.fp8) return false;
+    if (p.N != 256 || (p.K != 256 && p.K != 512) || p.M < 1) return false;
+    if (p.accumulate || p.mask_ref || p.act_relu || p.y_bf16 || p.film_g || p.y_row_group) return false;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || !al16(p.res) || !al16(p.ln_y) || p.ldx % 8 || p.ldw % 8 || p.ldy % 4 || p.ldres % 4) return false;
+    if (p.drop.p > 0.f && p.drop_ld % 2) return false;
+    return true;
+}
+
+int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    GG_REQUIRE(wst_ln_supported(p), "wst_ln: unsupported shape / alignment");
+    if (p.K == 256) return launch<4, 2, 16>(p, st, ev0, ev1);
+    return launch<8, 1, 32>(p, st, ev0, ev1);
+}
+
+// the other token-tall Linears of the production width that have a weight-stationary instantiation:
+//   1  y (fp32) += X W^T, N = 256, K = 512, bf16 X                       (dx1 += dh W1)
+//   2  y (bf16) = drop(relu(X W^T + b)), N = 512, K = 256, fp32 X        (FFN1 forward)
+//   3  y (bf16) = (X W^T) gated by ref, N = 512, K = 256, bf16 X          (dh = dres W2 * [h > 0])
+//   4  y (bf16) = act(X W^T + b), N = 256, K = 256, bf16 X              (dctx = dres Wo)
+//   5  as 1 with K = 768                                                 (dx += dqkv Win)
+int wst_kind(const TlinP& p) {
+    if (p.fp8 || p.ln_g || p.res || p.film_g || p.y_row_group || p.M < 1) return 0;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 8 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
+    if (p.drop.p > 0.f && p.drop_ld % 2) return 0;
+    // K = 768 (dx += dqkv Win) has an instantiation (case 5) but its 192 weight registers leave no room: 172 B of spills per
+    // lane, 1.96 ms against 1.67 ms for the token-on-lane kernel at cfg3 - it stays there
+    static const bool k768 = getenv("GG_WST_K768") != nullptr;
+    if (p.accumulate && !p.mask_ref && !p.act_relu && !p.y_bf16 && p.x_bf16 && p.N == 256 && (p.K == 512 || (k768 && p.K == 768)) &&
+        p.drop.p == 0.f && !p.bias && p.ldy % 4 == 0)
+        return p.K == 512 ? 1 : 5;
+    if (!p.accumulate && !p.mask_ref && p.y_bf16 && p.x_bf16 && p.N == 256 && p.K == 256 && p.ldy % 8 == 0) return 4;
+    if (!p.accumulate && !p.mask_ref && p.y_bf16 && !p.x_bf16 && p.N == 512 && p.K == 256 && p.ldy % 8 == 0) return 2;
+    if (!p.accumulate && p.mask_ref && p.mask_bf16 && p.y_bf16 && p.x_bf16 && p.N == 512 && p.K == 256 && !p.act_relu &&
+        p.drop.p == 0.f && !p.bias && p.ldy % 8 == 0 && p.ldref % 8 == 0 && al16(p.mask_ref))
+        return 3;
+    return 0;
+}
+int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    switch (wst_kind(p)) {
+        case 1: return launch<8, 1, 32, true, EPI_ACC>(p, st, ev0, ev1);
+        case 2: return launch<8, 2, 16, false, EPI_ACT>(p, st, ev0, ev1);
+        case 3: return launch<8, 2, 16, true, EPI_MASK>(p, st, ev0, ev1);
+        case 4: return launch<4, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
+        case 5: return launch<8, 1, 48, true, EPI_ACC>(p, st, ev0, ev1);
+    }
+    set_error("wst_other: no instantiation for this call");
+    return -2;
+}
+
+}  // namespace gg
