@@ -168,7 +168,9 @@ bool tlin_fp8_supported(const TlinP& p);
 bool wst_ln_supported(const TlinP& p);
 int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int wst_kind(const TlinP& p);          // 0: none; 1 += (N 256, K 512); 2 relu/dropout -> bf16 (N 512, K 256, fp32 X); 3 gated -> bf16
-int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);            // p.fp8 set and one of the fp8 instantiations takes the shape
+int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int wst_fp8_kind(const TlinP& p);      // fp8 operands: 0 none; 1 / 2 LN (K 256 / 512); 3 FFN1 (N 512); 4 QKV (N 768)
+int wst_fp8(const TlinP& p, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);            // p.fp8 set and one of the fp8 instantiations takes the shape
 int tlin(const TlinP& p, hipStream_t st);
 void tlin_time_next(hipEvent_t begin, hipEvent_t end);     // the next tlin() launch stamps these at the kernel's own begin / end
 // 0 stream (K != 256), 1 resident 32-token, 2/3/4 resident 16-token (+res+LN / += / other),

@@ -19,6 +19,7 @@
 //                                  enables the fused residual + LayerNorm epilogue (N = E).
 #include "kernels.h"
 #include "drop_rng.h"
+#include "fp8_util.h"
 #include <type_traits>
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -137,20 +138,6 @@ __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, in
 // operands undo the two power-of-two scales inside the instruction (scale byte = 127 - exponent), so accumulators,
 // epilogues and outputs are exactly those of the bf16 kernels.  A lane's fragment is 32 CONSECUTIVE k (32 bytes): lane
 // (c, g) of a 16x16x128 holds k = 32 g .. 32 g + 31 of row / column c, lane (c, h) of a 32x32x64 k = 32 h .. 32 h + 31.
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned cvt4_fp8(float a, float b, float c, float d, float sc) {
-    a = __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f);
-    b = __builtin_amdgcn_fmed3f(b * sc, -448.f, 448.f);
-    c = __builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f);
-    d = __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f);
-    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-    return (unsigned)r;
-}
-__device__ __forceinline__ i32x8 lds_frag32(const unsigned char* q) {
-    const u32x4 lo = *reinterpret_cast<const u32x4*>(q), hi = *reinterpret_cast<const u32x4*>(q + 16);
-    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-}
 // rows [tok0, tok0+ROWS) x [k0, k0+W) of X (fp32 or bf16) as e4m3 bytes into the slab xs (row stride LD bytes)
 template <int W, int LD, bool XB, int ROWS>
 __device__ __forceinline__ void stage_x8(const TlinP& p, unsigned char* xs, int tok0, int last_tok, int k0, int lane, float sc) {
@@ -191,7 +178,6 @@ __device__ __forceinline__ void stage_x8(const TlinP& p, unsigned char* xs, int 
         }
     }
 }
-__device__ __forceinline__ float exp2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 // ---- resident: all N = 32*NT_RES accumulators in registers, K streamed in slices of KSL ------------------------
 // PRE: what the epilogue adds to the product, prefetched while the last slice is multiplied:
@@ -980,7 +966,11 @@ bool wst_routed(const TlinP& p) {
 // classes >= 32: kernels outside the tlin_str_kernel<256, XB, YB, EPI> family (engine.hip try_tlin names them)
 int tlin_kernel_class(const TlinP& p) {
     if (wst_routed(p)) return wst_ln_supported(p) ? (p.K == 256 ? 32 : 33) : 33 + wst_kind(p);      // 32 .. 38
-    if (p.fp8) return p.ln_g ? 39 : (p.drop.p > 0.f ? 41 : 40);
+    if (p.fp8) {
+        static const bool no_wst8 = getenv("GG_NO_WST") != nullptr || getenv("GG_NO_WST8") != nullptr;
+        if (!no_wst8 && wst_fp8_kind(p)) return 41 + wst_fp8_kind(p);        // 42 .. 45
+        return p.ln_g ? 39 : (p.drop.p > 0.f ? 41 : 40);
+    }
     if (!needs_resident(p)) {
         if (p.K != 256) return 0;
         // 16 + the <XB, YB, EPI> instantiation launch_str_256 picks: bit 0 XB, bit 1 YB, bits 2..3 EPI
@@ -1015,6 +1005,12 @@ int tlin(const TlinP& p_in, hipStream_t st) {
     TlinP p = p_in;
     p.dbg = dbg;
     if (p.fp8) {
+        static const bool no_wst8 = getenv("GG_NO_WST") != nullptr || getenv("GG_NO_WST8") != nullptr;
+        if (!no_wst8 && wst_fp8_kind(p)) {
+            hipEvent_t a = g_ev0, b = g_ev1;
+            g_ev0 = g_ev1 = nullptr;
+            return wst_fp8(p, st, a, b);
+        }
         GG_REQUIRE(tlin_fp8_supported(p), "tlin: shape has no fp8 instantiation");
         return launch_fp8(p, st);
     }

@@ -21,6 +21,7 @@
 // y = (X W^T) * [ref > 0] * scale -> bf16 (dh = (dres W2) gated by the stored hidden activations).
 #include "kernels.h"
 #include "drop_rng.h"
+#include "fp8_util.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
@@ -43,16 +44,21 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN>
+// F8: e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (see tlin.hip "fp8 operand path"): W from the e4m3 shadow (half the
+// weight registers: N = 768 fits), X quantised to e4m3 while staging, a lane's fragment = 32 consecutive k (32 bytes).
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false>
 __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     constexpr int K = 16 * KS, N = 32 * NW * RT, NTH = 64 * NW;
-    constexpr int XLD = K + 8;                          // bf16 per LDS row: 4 banks per row step, conflict-free 16-byte reads
+    constexpr int ESZ = F8 ? 1 : 2;                     // bytes per operand element in LDS
+    constexpr int XLD = F8 ? K + 16 : K + 8;            // elements per LDS row: 4 banks per row step, conflict-free 16-byte reads
+    constexpr int KS8 = K / 64;                         // k-steps of the fp8 instruction
     constexpr int PPR = XB ? K / 8 : K / 4;             // 16-byte pieces per row of X as stored in memory
     constexpr int XP = TT * PPR / NTH;                  // pieces per thread and tile
     static_assert(TT * PPR % NTH == 0, "tile staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* const Xs = reinterpret_cast<__bf16*>(smem_raw);                        // [2][TT * XLD]
-    float* const Red = reinterpret_cast<float*>(Xs + 2 * TT * XLD);                // [2][NW][TT][2]  (sum, sum of squares)
+    unsigned char* const Xs8 = smem_raw;                                           // the same image in fp8 mode (bytes)
+    float* const Red = reinterpret_cast<float*>(smem_raw + 2 * TT * XLD * ESZ);    // [2][NW][TT][2]  (sum, sum of squares)
     float* const Ps = Red + 2 * NW * TT * 2;                                       // bias | gamma | beta  [3][N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -62,8 +68,20 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     const int last_tok = (int)p.M - 1;
 
     // resident weights: A fragment of k-step s for row tile rt = W[f0 + 32 rt + a_row_of_lane(c)][16 s + 8 h .. + 7]
-    bf16x8 wA[RT][KS];
-    {
+    bf16x8 wA[F8 ? 1 : RT][F8 ? 1 : KS];
+    i32x8 wA8[F8 ? RT : 1][F8 ? KS8 : 1];
+    if constexpr (F8) {
+        const unsigned char* Wp = reinterpret_cast<const unsigned char*>(p.W);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned char* wr = Wp + (long)(f0 + 32 * rt + a_row_of_lane(c)) * p.ldw + 32 * h;
+#pragma unroll
+            for (int s = 0; s < KS8; ++s) {
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(wr + 64 * s), hi = *reinterpret_cast<const u32x4*>(wr + 64 * s + 16);
+                wA8[rt][s] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+        }
+    } else {
         const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -72,6 +90,8 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
             for (int s = 0; s < KS; ++s) wA[rt][s] = *reinterpret_cast<const bf16x8*>(wr + 16 * s);
         }
     }
+    const int sc_w = F8 ? 127 - *p.w_exp : 0, sc_x = F8 ? 127 - p.x_exp : 0;
+    const float xscale = F8 ? exp2i(p.x_exp) : 1.f;
     for (int i = tid; i < N; i += NTH) {
         Ps[i] = p.bias ? p.bias[i] : 0.f;
         if constexpr (EPI == EPI_LN) {
@@ -95,7 +115,19 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int f = tid + NTH * i, row = f / PPR, pc = f % PPR;
-            if constexpr (XB) {
+            if constexpr (F8 && XB) {          // 8 bf16 -> 8 e4m3
+                float f8[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f8[2 * j] = __builtin_bit_cast(float, xr[i][j] << 16);
+                    f8[2 * j + 1] = __builtin_bit_cast(float, xr[i][j] & 0xffff0000u);
+                }
+                *reinterpret_cast<u32x2*>(&Xs8[buf * TT * XLD + row * XLD + 8 * pc]) =
+                    u32x2{cvt4_fp8(f8[0], f8[1], f8[2], f8[3], xscale), cvt4_fp8(f8[4], f8[5], f8[6], f8[7], xscale)};
+            } else if constexpr (F8) {         // 4 fp32 -> 4 e4m3
+                const f32x4 v = __builtin_bit_cast(f32x4, xr[i]);
+                *reinterpret_cast<unsigned*>(&Xs8[buf * TT * XLD + row * XLD + 4 * pc]) = cvt4_fp8(v[0], v[1], v[2], v[3], xscale);
+            } else if constexpr (XB) {
                 *reinterpret_cast<u32x4*>(&Xs[buf * TT * XLD + row * XLD + 8 * pc]) = xr[i];
             } else {        // fp32 in memory, bf16 in LDS
                 const f32x4 v = __builtin_bit_cast(f32x4, xr[i]);
@@ -149,12 +181,23 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
-        const __bf16* xb = Xs + buf * TT * XLD + c * XLD + 8 * h;
+        if constexpr (F8) {
+            const unsigned char* xb8 = Xs8 + buf * TT * XLD + c * XLD + 32 * h;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
+            for (int s = 0; s < KS8; ++s) {
+                const i32x8 xf = lds_frag32(xb8 + 64 * s);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[rt][s], xf, acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wA8[rt][s], xf, acc[rt], 0, 0, 0, sc_w, 0, sc_x);
+            }
+        } else {
+            const __bf16* xb = Xs + buf * TT * XLD + c * XLD + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + 16 * s);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[rt][s], xf, acc[rt], 0, 0, 0);
+            }
         }
         // the next tile's rows (already in registers) go to the other buffer, the tile after that is requested
         if (tile + gridDim.x < ntiles) {
@@ -272,14 +315,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     }
 }
 
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN>
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false>
 int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int K = 16 * KS, N = 32 * NW * RT;
-    constexpr size_t smem = (size_t)2 * TT * (K + 8) * 2 + (size_t)2 * NW * TT * 2 * 4 + (size_t)3 * N * 4;
+    constexpr size_t smem = (size_t)2 * TT * (F8 ? K + 16 : (K + 8) * 2) + (size_t)2 * NW * TT * 2 * 4 + (size_t)3 * N * 4;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int dev = 0;
         GG_CHECK_HIP(hipGetDevice(&dev));
         GG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -288,8 +331,8 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const long ntiles = (p.M + TT - 1) / TT;
     const long slots = (long)n_cu * (NW == 4 ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8
     const unsigned grid = (unsigned)std::min<long>(ntiles, slots);
-    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
-    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI>), dim3(grid), dim3(64 * NW), smem, st, p);
+    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
+    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), dim3(grid), dim3(64 * NW), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -334,6 +377,30 @@ int wst_kind(const TlinP& p) {
         p.drop.p == 0.f && !p.bias && p.ldy % 8 == 0 && p.ldref % 8 == 0 && al16(p.mask_ref))
         return 3;
     return 0;
+}
+// fp8 mode (p.fp8, e4m3 shadow weights): 1 / 2 Linear + dropout + residual + LayerNorm (K = 256 / 512), 3 FFN1 (N = 512, fp32 X),
+// 4 the packed QKV projection (N = 768, fp32 X: 96 weight registers per lane as e4m3, out of reach in bf16)
+int wst_fp8_kind(const TlinP& p) {
+    if (!p.fp8 || !p.w_exp || p.film_g || p.y_row_group || p.mask_ref || p.accumulate || p.M < 1) return 0;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 16 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
+    if (p.drop.p > 0.f && p.drop_ld % 2) return 0;
+    if (p.ln_g) {
+        if (!(p.ln_b && p.ln_y && p.ln_stats && p.res && p.x_bf16 && !p.act_relu && !p.y_bf16 && p.N == 256)) return 0;
+        if (!al16(p.res) || !al16(p.ln_y) || p.ldy % 4 || p.ldres % 4) return 0;
+        return p.K == 256 ? 1 : (p.K == 512 ? 2 : 0);
+    }
+    if (p.res || !p.y_bf16 || p.x_bf16 || p.K != 256 || p.ldy % 8) return 0;
+    return p.N == 512 ? 3 : (p.N == 768 ? 4 : 0);
+}
+int wst_fp8(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    switch (wst_fp8_kind(p)) {
+        case 1: return launch<4, 2, 16, true, EPI_LN, true>(p, st, ev0, ev1);
+        case 2: return launch<8, 1, 32, true, EPI_LN, true>(p, st, ev0, ev1);
+        case 3: return launch<8, 2, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
+        case 4: return launch<8, 3, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
+    }
+    set_error("wst_fp8: no instantiation for this call");
+    return -2;
 }
 int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     switch (wst_kind(p)) {
