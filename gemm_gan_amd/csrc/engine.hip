@@ -156,6 +156,7 @@ struct gg_engine {
     hipStream_t pre_stream = nullptr;
     hipEvent_t pre_fork = nullptr, pre_ev[GG_MAX_PREFETCH] = {};
     bool pre_wait[GG_MAX_PREFETCH] = {};
+    struct { const float* z_all; const gg_cond* in; int n, rmax; bool pending; } pre_rest = {nullptr, nullptr, 0, 0, false};
     float *c3;                 // [3B, E] conditioning rows for the critic head (fake, real, hat)
     float *Pfr;                // [2B, H] x @ W1x^T for fake / real
     float *dseed;              // [2B]
@@ -1450,7 +1451,24 @@ int prefetch_drain(Ctx& c) {        // the caller's stream waits for every outpu
         }
     return 0;
 }
-int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
+// the passes 1 .. n-1 of a pipelined prefetch, on the third stream in their own arena
+int prefetch_rest(gg_engine* e) {
+    if (!e->pre_rest.pending) return 0;
+    e->pre_rest.pending = false;
+    Ctx cp{e, e->pre_stream};
+    const int n = e->pre_rest.n, rmax = e->pre_rest.rmax;
+    for (int done = 1; done < n;) {
+        const int r = std::min(n - done, rmax);
+        GG_TRY(prefetch_chunk(cp, e->pre_rest.z_all, done, r, e->pre_rest.in, e->actsP, e->headP, e->c3P));
+        for (int k = done; k < done + r; ++k) {
+            GG_CHECK_HIP(hipEventRecord(e->pre_ev[k], e->pre_stream));
+            e->pre_wait[k] = true;
+        }
+        done += r;
+    }
+    return 0;
+}
+int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in, bool defer_rest = false) {
     gg_engine* e = c.e;
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     const int B = in->B;
@@ -1487,17 +1505,12 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in) {
     GG_TRY(prefetch_chunk(c, z_all, 0, 1, in, e->actsD, e->headD, e->c3));
     GG_CHECK_HIP(hipEventRecord(e->pre_fork, c.st));                        // after the shadow refresh and everything before it
     GG_CHECK_HIP(hipStreamWaitEvent(e->pre_stream, e->pre_fork, 0));
-    Ctx cp{e, e->pre_stream};
-    for (int done = 1; done < n;) {
-        const int r = std::min(n - done, rmax);
-        GG_TRY(prefetch_chunk(cp, z_all, done, r, in, e->actsP, e->headP, e->c3P));
-        for (int k = done; k < done + r; ++k) {
-            GG_CHECK_HIP(hipEventRecord(e->pre_ev[k], e->pre_stream));
-            e->pre_wait[k] = true;
-        }
-        done += r;
-    }
     e->pre_n = n;
+    // The remaining passes are ENQUEUED later when the caller asks for it (gg_train_step: after the first critic iteration
+    // has been enqueued on the caller's stream): ~170 launches on the third stream take the host ~1 ms during which the
+    // caller's stream would have nothing to run whenever the host is not far ahead of the GPU.
+    e->pre_rest = {z_all, in, n, rmax, true};
+    if (!defer_rest) GG_TRY(prefetch_rest(e));
     return 0;
 }
 // next stored generator output (nullptr: none); the caller's stream waits for it if it is still being computed
@@ -1835,12 +1848,15 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const fl
     Ctx c{e, (hipStream_t)stream};
     e->launches = 0;
     const long zs = (long)in->B * e->L;
-    if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in));
+    static const bool defer = getenv("GG_NO_PREFETCH_DEFER") == nullptr;
+    if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in, defer));
     for (int k = 0; k < n_critic; ++k) {
+        if (k == 1) GG_TRY(prefetch_rest(e));           // (no-op unless deferred) output 1 is waited for just below
         GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(c, in->B)));
         e->dcond_valid = false;
         GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
     }
+    GG_TRY(prefetch_rest(e));
     e->pre_n = e->pre_next = 0;
     GG_TRY(generator_backward(c, z_all + n_critic * zs, in, losses));
     GG_TRY(apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, 1.f));

@@ -7,8 +7,7 @@ def nm(r):
     n = r["Kernel_Name"].replace("gg::(anonymous namespace)::", "").replace("void ", "").replace("gg::", "")
     return re.sub(r"\(.*", "", n)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first_f32 = next((i for i, r in enumerate(rows) if "gemm_f32_kernel" in r["Kernel_Name"]), len(rows))
-bf = rows[:first_f32]
+bf = rows          # run bench.py with --no-parity-mode: the whole trace is the bf16 run
 eng = [r for r in bf if any(k in r["Kernel_Name"] for k in ("tlin_", "attn_", "wgrad_", "gemm_small"))] or bf
 t_end = max(int(r["End_Timestamp"]) for r in eng)            # the last engine kernel: host-side epilogue work is not a step
 t0 = t_end - int(steps * ms * 1e6)
