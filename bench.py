@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=0, help="timed CPU steps (0: as many as fit in ~20 s, at most 12)")
     ap.add_argument("--parity-steps", type=int, default=10, help="timed steps of the f32 reference-precision figure")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay gg_train_step from its captured hipGraph (N=1) instead of enqueueing it kernel by kernel; "
+                         "measured slower on ROCm 7.2, hence opt-in (DESIGN.md section 6)")
     return ap.parse_args()
 
 
@@ -187,6 +190,9 @@ def main():
                 precision=args.precision)
     w.build_WGAN_GP()
     w.init_train()
+    if args.graph:
+        w.use_graph = True
+        w.engine.set_graph(True)
     w.reserve(B, P, T)
     g = torch.Generator(device=dev).manual_seed(42 + rank)   # per-rank shard of the global minibatch
     x = torch.randn(B, G, device=dev, generator=g)
@@ -300,6 +306,7 @@ def main():
                                       f"n_critic=5, rms_prop, dropout {args.dropout}"
                                       + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count(),
+                          "hip_graph": w.engine.graph_stats() if w.engine.graph else None,
                           "allreduce_wait_ms_per_step": round(comm_ms, 3) if world > 1 else None},
                "finite": finite,
                "losses": {"d": losses_head[0], "g": losses_head[1]}}

@@ -64,6 +64,8 @@ SYMBOLS = {
     "gg_generator_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "gg_generator_prefetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GGCond), C.c_void_p]),
     "gg_set_prefetch": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gg_set_side_streams": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gg_set_lr": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),

@@ -163,7 +163,8 @@ __device__ __forceinline__ bf16x8 frag_transposed(const __bf16* img, int ld, int
 template <int DH, bool IOB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                        int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
-                                                       int S, int E, int nh, DropKey drop, int qkv_B) {
+                                                       int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
 template <int DH, bool IOB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                        int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
-                                                       int S, int E, int nh, DropKey drop, int qkv_B, int CK, int npairs, int nqg) {
+                                                       int S, int E, int nh, DropKey drop_in, int qkv_B, int CK, int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -523,7 +525,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
                                                           const void* __restrict__ dctx,
                                                           const float* __restrict__ lse2, float* __restrict__ delta,
                                                           const uint8_t* __restrict__ mask, int mask_B,
-                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B) {
+                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
@@ -685,7 +688,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const void* __rest
                                                               const void* __restrict__ dctx,
                                                               const float* __restrict__ lse2, float* __restrict__ delta,
                                                               const uint8_t* __restrict__ mask, int mask_B,
-                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B) {
+                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     const int nqt = Sp / 32, nkt = Sp / 32;
@@ -887,7 +891,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
                                                               const void* __restrict__ dctx,
                                                               const float* __restrict__ lse2, float* __restrict__ delta,
                                                               const uint8_t* __restrict__ mask, int mask_B,
-                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop, int qkv_B, int CK, int npairs, int nqg) {
+                                                              void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B, int CK, int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     const int nqt = Sp / 32, nkt = Sp / 32;
@@ -1071,8 +1076,9 @@ template <int DH, bool IOB>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restrict__ qkv, const void* __restrict__ dctx,
                                                            const float* __restrict__ lse2, const float* __restrict__ delta,
                                                            const uint8_t* __restrict__ mask, int mask_B,
-                                                           void* __restrict__ dqkv, int S, int E, int nh, DropKey drop,
+                                                           void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in,
                                                            long total_items, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
     constexpr int LDR = DH + 8;      // row-major tile [32][DH+8] bf16
     constexpr int DT = (DH + 31) / 32;
     constexpr int KS = DH / 16;

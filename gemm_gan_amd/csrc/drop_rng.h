@@ -28,6 +28,16 @@ __device__ __forceinline__ uint32_t drop_fmix32(uint32_t h) {
 #endif
     return h;
 }
+// The key a kernel works with: k0 re-mixed with the engine's device-side epoch word (see DropKey::epoch), once per thread
+// at kernel entry (a scalar load + 5 scalar ALU ops).  Forward and backward kernels of a step read the same word.
+__device__ __forceinline__ DropKey drop_live(DropKey k) {
+    if (k.epoch) {
+        uint32_t h = k.k0 + __builtin_nontemporal_load(k.epoch) * 0x632BE5ABu;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        k.k0 = h;
+    }
+    return k;
+}
 // pre-mix state of element pair `pair` (= element index >> 1)
 __device__ __forceinline__ uint32_t drop_state(const DropKey& k, uint64_t pair) { return (uint32_t)pair * DROP_PHI + k.k0; }
 // the two 16-bit uniforms of a pair: low half -> even element, high half -> odd element

@@ -183,6 +183,26 @@ struct gg_engine {
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
     float *s_dt, *s_dp, *s_dq, *s_dq2, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
+    // ---- captured train step (hipGraph) ----
+    // device words: [0] dropout epoch (DropKey::epoch), [1 + role] offset added to the Adam step number baked into a
+    // captured optimiser launch; written by one tiny eager kernel ahead of every replay
+    uint32_t* dev_words = nullptr;
+    struct StepGraph {
+        std::vector<uint64_t> sig;      // everything a captured step bakes in: pointers, shapes, hyper-parameters
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;                   // eager runs with this signature so far (capture happens on the second sight)
+        bool bad = false;               // capture failed once: stay eager
+        uint32_t calls = 0;             // forward passes (dropout call numbers) one step consumes
+        int t0[2] = {0, 0}, tsteps[2] = {0, 0};   // optimiser step numbers at capture, steps per replay
+        int64_t launches = 0;
+        uint64_t last_use = 0;
+    };
+    std::vector<StepGraph> graphs;
+    bool graph_on = false, capturing = false;
+    hipStream_t cap_stream = nullptr;
+    uint32_t epoch_host = 0;
+    uint64_t graph_clock = 0;
+    int64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
     // live profiling
     bool prof_on = false;
     unsigned prof_mask = 0xffffffffu;      // kernel classes that get event pairs (bit = class id)
@@ -198,6 +218,12 @@ struct gg_engine {
 };
 
 namespace {
+
+void drop_graphs(gg_engine* e) {
+    for (auto& g : e->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
 
 // ------------------------------------------------------------------------------------------------
 // layout
@@ -383,7 +409,8 @@ size_t carve(gg_engine* e, void* base) {
     e->gp_grad = a.take<float>(B * G); e->gp_nrm2 = a.take<float>(B); e->gp_coef = a.take<float>(B);
     e->gp_dg1 = a.take<float>(B * H); e->gp_dg2 = a.take<float>(B * H);
     e->dxfake = a.take<float>(B * G);
-    e->sumsq = a.take<float>(2 * 1024 + 8);      // per network: <= 1024 partial sums of squares (k_sumsq); [2048..] scratch
+    e->sumsq = a.take<float>(2 * 1024 + 8);
+    e->dev_words = reinterpret_cast<uint32_t*>(a.take<float>(16));      // per network: <= 1024 partial sums of squares (k_sumsq); [2048..] scratch
     e->sPd = a.take<float>(RB * nh * S * S);
     e->sdP = a.take<float>(Rb * nh * S * S);
     e->sdqkv = a.take<float>(Rb * S * 3 * E);
@@ -640,7 +667,9 @@ int try_tlin(Ctx& c, const TlinP& p) {
     } while (0)
 
 DropKey dkey(gg_engine* e, const CondActs& a, int net, int layer, int site) {
-    return make_drop_key(a.drop, e->seed, (uint32_t)(net * 1000 + layer * 10 + site), a.call);
+    DropKey k = make_drop_key(a.drop, e->seed, (uint32_t)(net * 1000 + layer * 10 + site), a.call);
+    if (a.drop > 0.f) k.epoch = e->dev_words;
+    return k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1313,7 +1342,8 @@ int apply_opt(Ctx& c, Net& n, float max_norm, float grad_scale) {
     int n_partials = 0;
     if (max_norm > 0.f) KL(k_sumsq(n.g, n.live, ss, &n_partials, c.st));
     n.step_t += 1;
-    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.live, e->cfg.optimizer, n.lr, max_norm, ss, n_partials, grad_scale, n.step_t, c.st));
+    KL(k_opt_step(n.w, n.g, n.s1, n.s2, n.live, e->cfg.optimizer, n.lr, max_norm, ss, n_partials, grad_scale, n.step_t,
+                  e->capturing ? e->dev_words + 1 + n.role : nullptr, c.st));
     return 0;
 }
 
@@ -1648,6 +1678,8 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
 
 void gg_destroy(gg_engine* e) {
     if (!e) return;
+    drop_graphs(e);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->pre_stream) {
         (void)hipStreamSynchronize(e->pre_stream);
         (void)hipEventDestroy(e->pre_fork);
@@ -1694,6 +1726,8 @@ int gg_bind_workspace(gg_engine* e, void* ws, size_t bytes) {
     GG_REQUIRE((uintptr_t)ws % 256 == 0, "workspace must be 256-byte aligned");
     e->ws = ws;
     carve(e, ws);
+    drop_graphs(e);
+    GG_CHECK_HIP(hipMemset(e->dev_words, 0, 16 * sizeof(uint32_t)));
     for (int r = 0; r < 2; ++r) {
         Net& n = e->net[r];
         if (!n.tab.empty())
@@ -1840,12 +1874,10 @@ int gg_generator_apply(gg_engine* e, float grad_scale, void* stream) {
     return apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, grad_scale);
 }
 
-int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const float* z_all, const float* alpha_all,
-                  int n_critic, float* losses, void* stream) {
-    GG_REQUIRE(e && x_real && z_all && alpha_all && losses, "null argument");
-    GG_REQUIRE(n_critic >= 0, "bad n_critic");
-    GG_TRY(check_cond(e, in));
-    Ctx c{e, (hipStream_t)stream};
+namespace {
+int train_step_body(Ctx& c, const float* x_real, const gg_cond* in, const float* z_all, const float* alpha_all, int n_critic,
+                    float* losses) {
+    gg_engine* e = c.e;
     e->launches = 0;
     const long zs = (long)in->B * e->L;
     static const bool defer = getenv("GG_NO_PREFETCH_DEFER") == nullptr;
@@ -1860,6 +1892,121 @@ int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const fl
     e->pre_n = e->pre_next = 0;
     GG_TRY(generator_backward(c, z_all + n_critic * zs, in, losses));
     GG_TRY(apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, 1.f));
+    return 0;
+}
+
+// Everything a captured step freezes: if any of it differs, it is another graph.
+void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, const float* z_all,
+                    const float* alpha_all, int n_critic, const float* losses, std::vector<uint64_t>& v) {
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
+    v = {
+        (uint64_t)(uintptr_t)x_real, (uint64_t)(uintptr_t)z_all, (uint64_t)(uintptr_t)alpha_all, (uint64_t)(uintptr_t)losses,
+        (uint64_t)(uintptr_t)in->patches, (uint64_t)(uintptr_t)in->patch_pad, (uint64_t)(uintptr_t)in->text,
+        (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
+        (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
+            (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16,
+        bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
+    for (int r = 0; r < 2; ++r)
+        for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
+}
+
+__global__ void set_words_k(uint32_t* w, uint32_t a, uint32_t b, uint32_t c) { w[0] = a; w[1] = b; w[2] = c; }
+
+constexpr size_t GG_MAX_GRAPHS = 8;
+}  // namespace
+
+int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* in, const float* z_all, const float* alpha_all,
+                  int n_critic, float* losses, void* stream) {
+    GG_REQUIRE(e && x_real && z_all && alpha_all && losses, "null argument");
+    GG_REQUIRE(n_critic >= 0, "bad n_critic");
+    GG_TRY(check_cond(e, in));
+    Ctx c{e, (hipStream_t)stream};
+    if (!e->graph_on || e->prof_on) return train_step_body(c, x_real, in, z_all, alpha_all, n_critic, losses);
+
+    // ---- captured step: first sight of a signature runs eagerly (lazy initialisation happens there), the second is
+    // captured, later ones replay.  A caller whose buffers move every step never reaches the second sight: it stays eager.
+    std::vector<uint64_t> sig;
+    step_signature(e, x_real, in, z_all, alpha_all, n_critic, losses, sig);
+    gg_engine::StepGraph* g = nullptr;
+    for (auto& q : e->graphs)
+        if (q.sig == sig) { g = &q; break; }
+    if (!g) {
+        if (e->graphs.size() >= GG_MAX_GRAPHS) {
+            size_t old = 0;
+            for (size_t i = 1; i < e->graphs.size(); ++i)
+                if (e->graphs[i].last_use < e->graphs[old].last_use) old = i;
+            if (e->graphs[old].exec) (void)hipGraphExecDestroy(e->graphs[old].exec);
+            e->graphs.erase(e->graphs.begin() + (long)old);
+        }
+        e->graphs.emplace_back();
+        g = &e->graphs.back();
+        g->sig = sig;
+    }
+    g->last_use = ++e->graph_clock;
+    if (g->bad || g->seen++ == 0) return train_step_body(c, x_real, in, z_all, alpha_all, n_critic, losses);
+
+    uint32_t toff[2] = {0, 0};
+    if (!g->exec) {
+        if (!e->cap_stream) GG_CHECK_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        const uint32_t call0 = e->call_counter;
+        const int t0[2] = {e->net[0].step_t, e->net[1].step_t};
+        GG_CHECK_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+        Ctx cc{e, e->cap_stream};
+        e->capturing = true;
+        const int rc = train_step_body(cc, x_real, in, z_all, alpha_all, n_critic, losses);
+        e->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t ec = hipStreamEndCapture(e->cap_stream, &graph);
+        hipError_t ei = hipErrorUnknown;
+        if (rc == 0 && ec == hipSuccess && graph) ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) {     // nothing ran: restore the host-side counters and take the eager route from now on
+            (void)hipGetLastError();
+            g->exec = nullptr;
+            g->bad = true;
+            e->graph_failures++;
+            e->call_counter = call0;
+            e->net[0].step_t = t0[0]; e->net[1].step_t = t0[1];
+            for (bool& b : e->side_pending) b = false;
+            for (bool& b : e->pre_wait) b = false;
+            e->pre_rest.pending = false;
+            e->pre_n = e->pre_next = 0;
+            e->dcond_valid = false;
+            if (rc != 0) return rc;
+            return train_step_body(c, x_real, in, z_all, alpha_all, n_critic, losses);
+        }
+        g->calls = e->call_counter - call0;
+        for (int r = 0; r < 2; ++r) { g->t0[r] = t0[r]; g->tsteps[r] = e->net[r].step_t - t0[r]; }
+        g->launches = e->launches;
+        e->graph_captures++;
+    } else {
+        e->call_counter += g->calls;
+        for (int r = 0; r < 2; ++r) {
+            toff[r] = (uint32_t)(e->net[r].step_t - g->t0[r]);
+            e->net[r].step_t += g->tsteps[r];
+        }
+        e->launches = g->launches;
+        e->pre_n = e->pre_next = 0;
+        e->dcond_valid = false;
+        e->graph_replays++;
+    }
+    hipLaunchKernelGGL(set_words_k, dim3(1), dim3(1), 0, c.st, e->dev_words, ++e->epoch_host, toff[0], toff[1]);
+    GG_CHECK_HIP(hipGraphLaunch(g->exec, c.st));
+    return 0;
+}
+
+int gg_set_graph(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->graph_on = on != 0;
+    if (!on) drop_graphs(e);
+    return 0;
+}
+int gg_graph_stats(const gg_engine* e, int64_t* captures, int64_t* replays, int64_t* failures) {
+    GG_REQUIRE(e, "null argument");
+    if (captures) *captures = e->graph_captures;
+    if (replays) *replays = e->graph_replays;
+    if (failures) *failures = e->graph_failures;
     return 0;
 }
 

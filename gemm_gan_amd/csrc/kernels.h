@@ -10,6 +10,9 @@ struct DropKey {
     float p = 0.f;          // drop probability; 0 => disabled
     uint32_t k0 = 0;        // 32-bit mix of (seed, site, call)
     uint32_t thr = 0;       // round(p * 65536): element kept iff its 16-bit uniform >= thr
+    // Device word mixed into k0 by every kernel at its start (drop_live): 0 for eagerly enqueued work, the replay number
+    // of a captured train step (hipGraph: kernel arguments, hence k0, are frozen at capture) - fresh masks per replay.
+    const uint32_t* epoch = nullptr;
 };
 DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call);
 
@@ -220,6 +223,7 @@ enum OptKind { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_ADAMW = 2 };
 // one fixed order by every workgroup).  grad_scale is an extra factor applied to every gradient first (1/world_size after
 // a sum all-reduce).
 int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-               const float* partials, int n_partials, float grad_scale, int step_t, hipStream_t st);
+               const float* partials, int n_partials, float grad_scale, int step_t, const uint32_t* t_off, hipStream_t st);
+// (t_off: optional device word added to step_t for the Adam bias corrections, which are computed on the device)
 
 }  // namespace gg

@@ -249,7 +249,8 @@ int k_build_mask(const uint8_t* pad, uint8_t* mask_out, int B, int P, hipStream_
 
 // ---- softmax over rows (one wave per row, row cached in LDS) ----------------------------------------
 constexpr int SM_MAXC = 2048;
-__global__ __launch_bounds__(TPB) void softmax_rows_k(float* S, float* Pd, long rows, int cols, DropKey drop) {
+__global__ __launch_bounds__(TPB) void softmax_rows_k(float* S, float* Pd, long rows, int cols, DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     __shared__ float buf[4][SM_MAXC];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
@@ -284,7 +285,8 @@ int k_softmax_rows(float* S, float* Pd, long rows, int cols, DropKey drop, hipSt
     GG_LAUNCH_CHECK();
 }
 __global__ __launch_bounds__(TPB) void softmax_bwd_rows_k(float* dP, const float* P, long rows, int cols, float scale,
-                                                          DropKey drop) {
+                                                          DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     __shared__ float buf[4][SM_MAXC];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
@@ -313,7 +315,8 @@ constexpr float LN_EPS = 1e-5f;
 template <int NJ>
 __global__ __launch_bounds__(TPB) void add_ln_fwd_k(const float* x, long x_rows, float* res, const float* g,
                                                      const float* b, float* y, float* stats, long rows, int E,
-                                                     DropKey drop) {
+                                                     DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
@@ -372,7 +375,8 @@ int k_add_layernorm_fwd(const float* x, long x_rows, float* res, const float* g,
 template <int NJ>
 __global__ __launch_bounds__(TPB) void ln_bwd_k(const float* dy, const float* r, const float* stats, const float* g,
                                                  float* dr, float* dres, float* dgamma, float* dbeta, float* dbias,
-                                                 long rows, int E, DropKey drop) {
+                                                 long rows, int E, DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     float pg[NJ], pb[NJ], pc[NJ];
@@ -431,7 +435,8 @@ __device__ __forceinline__ unsigned pack2_k(float a, float b) {
 template <int NV>
 __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float* r, const float* stats, const float* g,
                                                     float* dr, void* dres, int dres_bf16, float* dgamma, float* dbeta,
-                                                    float* dbias, long rows, int E, DropKey drop) {
+                                                    float* dbias, long rows, int E, DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
     f32x4 pg[NV], pb[NV], pc[NV], gw[NV];
@@ -641,7 +646,8 @@ int k_bias_act(float* y, const float* bias, long rows, int N, int act, float slo
     bias_act_k<<<nblocks(rows * N, TPB, 16384), TPB, 0, st>>>(y, bias, rows, N, act, slope);
     GG_LAUNCH_CHECK();
 }
-__global__ void dropout_k(float* x, long n, DropKey drop) {
+__global__ void dropout_k(float* x, long n, DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     const float ks = 1.f / (1.f - drop.p);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         x[i] *= drop_factor(drop, (uint64_t)i, ks);
@@ -1049,7 +1055,8 @@ int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipSt
     gather_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(out, seq, B, P, E);
     GG_LAUNCH_CHECK();
 }
-__global__ void dropout_copy_k(float* out, const float* in, long n, DropKey drop) {
+__global__ void dropout_copy_k(float* out, const float* in, long n, DropKey drop_in) {
+    const DropKey drop = drop_live(drop_in);
     const float ks = 1.f / (1.f - drop.p);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = in[i] * drop_factor(drop, (uint64_t)i, ks);
@@ -1193,8 +1200,15 @@ int k_sumsq(const float* x, long n, float* partials, int* n_partials, hipStream_
     GG_LAUNCH_CHECK();
 }
 __global__ __launch_bounds__(TPB) void opt_step_k(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-                                                   const float* partials, int n_partials, float grad_scale, float bc1, float bc2s) {
+                                                   const float* partials, int n_partials, float grad_scale, int step_t,
+                                                   const uint32_t* __restrict__ t_off) {
     float coef = grad_scale;
+    float bc1 = 1.f, bc2s = 1.f;
+    if (kind != OPT_RMSPROP) {      // Adam bias corrections; t_off: see gg_engine::dev_words (captured steps)
+        const float t = (float)(step_t + (t_off ? (int)*t_off : 0));
+        bc1 = 1.f - powf(0.9f, t);
+        bc2s = sqrtf(1.f - powf(0.99f, t));
+    }
     if (max_norm > 0.f) {
         __shared__ float red[TPB / 64];
         __shared__ float tot;
@@ -1231,10 +1245,8 @@ __global__ __launch_bounds__(TPB) void opt_step_k(float* w, const float* g, floa
     }
 }
 int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind, float lr, float max_norm,
-               const float* partials, int n_partials, float grad_scale, int step_t, hipStream_t st) {
-    const float bc1 = 1.f - powf(0.9f, (float)step_t);
-    const float bc2s = sqrtf(1.f - powf(0.99f, (float)step_t));
-    opt_step_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(w, g, s1, s2, n, kind, lr, max_norm, partials, n_partials, grad_scale, bc1, bc2s);
+               const float* partials, int n_partials, float grad_scale, int step_t, const uint32_t* t_off, hipStream_t st) {
+    opt_step_k<<<nblocks(n, TPB, 8192), TPB, 0, st>>>(w, g, s1, s2, n, kind, lr, max_norm, partials, n_partials, grad_scale, step_t, t_off);
     GG_LAUNCH_CHECK();
 }
 

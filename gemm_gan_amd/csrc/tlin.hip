@@ -185,6 +185,7 @@ __device__ __forceinline__ void stage_x8(const TlinP& p, unsigned char* xs, int 
 enum { PRE_NONE = 0, PRE_RES = 1, PRE_ACC = 2, PRE_ANY = 3 };
 template <int NT_RES, int KSL, bool XB, int PRE>
 __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
+    const DropKey dkey = drop_live(p.drop);
     constexpr int N = 32 * NT_RES;
     constexpr int WLD = KSL + 8;                       // bf16 per LDS row (weights and activations)
     constexpr int PIECES = KSL / 8;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 v += bb;
                 if constexpr (DROP) {
                     float f[4];
-                    drop_factor4(p.drop, dbase + n, ksd, f);
+                    drop_factor4(dkey, dbase + n, ksd, f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int NT_RES, int KSL, bool XB, int PRE, bool F8 = false>
 __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
+    const DropKey dkey = drop_live(p.drop);
     constexpr int N = 32 * NT_RES;
     constexpr int NF = 2 * NT_RES;                     // 16-feature tiles
     constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void tlin_res16_kernel(const TlinP p) {
             f32x4 v = acc[t] + bb;
             if constexpr (DROP) {
                 float f[4];
-                drop_factor4(p.drop, dbase + 16 * t, ksd, f);
+                drop_factor4(dkey, dbase + 16 * t, ksd, f);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= f[j];
             }
@@ -597,6 +599,7 @@ enum { EPI_BIAS = 0, EPI_DROP = 1, EPI_MASK = 2, EPI_ANY = 3 };
 #endif
 template <int KSL, bool XB, bool YB, int EPI, bool F8 = false>
 __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p) {
+    const DropKey dkey = drop_live(p.drop);
     constexpr int XW = KSL < 128 ? KSL : 128;          // staging window (bounds LDS so two workgroups fit a CU)
     constexpr int ESZ = F8 ? 1 : 2;                    // operand bytes per element
     constexpr int XLDW = F8 ? XW + 32 : XW + 8;
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_);
             if (drop_on) {
                 float f[4];
-                drop_factor4(p.drop, dbase + n, ksd, f);
+                drop_factor4(dkey, dbase + n, ksd, f);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= f[j];
             }

@@ -48,6 +48,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // weight registers: N = 768 fits), X quantised to e4m3 while staging, a lane's fragment = 32 consecutive k (32 bytes).
 template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false>
 __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
+    const DropKey dkey = drop_live(p.drop);
     constexpr int K = 16 * KS, N = 32 * NW * RT, NTH = 64 * NW;
     constexpr int ESZ = F8 ? 1 : 2;                     // bytes per operand element in LDS
     constexpr int XLD = F8 ? K + 16 : K + 8;            // elements per LDS row: 4 banks per row step, conflict-free 16-byte reads
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
                         }
                         if (drop_on) {
                             float f[4];
-                            drop_factor4(p.drop, dbase2 + 32 * rt + 4 * g, ksd, f);
+                            drop_factor4(dkey, dbase2 + 32 * rt + 4 * g, ksd, f);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] *= f[j];
                         }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
                 v += bb;
                 if (drop_on) {
                     float f[4];
-                    drop_factor4(p.drop, dbase + 32 * rt + 4 * g, ksd, f);
+                    drop_factor4(dkey, dbase + 32 * rt + 4 * g, ksd, f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }

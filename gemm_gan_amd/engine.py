@@ -51,6 +51,7 @@ class Engine:
                 L.check(self.lib.gg_bind_net(self.h, r, _ptr(bufs["w"]), _ptr(bufs["g"]), _ptr(bufs["s1"]), _ptr(bufs["s2"])))
             self._alloc_workspace()
             self.losses = torch.zeros(L.N_LOSSES, dtype=torch.float32, device=self.device)
+            self.graph, self._stage, self._zeros = False, {}, {}
         self.dropout = float(dropout)
         self._keep_ring = []
         off, numel = C.c_int64(), C.c_int64()
@@ -214,10 +215,42 @@ class Engine:
     def set_prefetch(self, on):
         L.check(self.lib.gg_set_prefetch(self.h, int(bool(on))))
 
+    def zeros(self, *shape, dtype=torch.float32):
+        """A read-only all-zero tensor that lives as long as the engine (all-False masks and dummy conditioning inputs of the
+        sibling facades: the same address every call, so a resident batch keeps its captured graph)."""
+        key = (tuple(shape), dtype)
+        t = self._zeros.get(key)
+        if t is None:
+            t = self._zeros[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
+        return t
+
+    def set_graph(self, on):
+        """Replay gg_train_step from a captured hipGraph once a set of input buffers has been seen twice (gemmgan.h)."""
+        L.check(self.lib.gg_set_graph(self.h, int(bool(on))))
+        self.graph = bool(on)
+        self._stage = {}
+
+    def graph_stats(self):
+        v = [C.c_int64(0) for _ in range(3)]
+        L.check(self.lib.gg_graph_stats(self.h, *[C.byref(x) for x in v]))
+        return {"captures": v[0].value, "replays": v[1].value, "failures": v[2].value}
+
+    def _staged(self, name, t):
+        """A captured step reads its inputs from the addresses it was captured with: the per-step noise goes through
+        engine-lifetime buffers (two small copies per step)."""
+        key = (name, tuple(t.shape))
+        buf = self._stage.get(key)
+        if buf is None:
+            buf = self._stage[key] = torch.empty_like(t)
+        buf.copy_(t)
+        return buf
+
     def train_step(self, x_real, patches, patch_pad, text, text_pad, z_all, alpha_all):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         n_critic = alpha_all.shape[0]
         assert z_all.shape[0] == n_critic + 1 and z_all.is_contiguous() and alpha_all.is_contiguous()
+        if getattr(self, "graph", False):
+            z_all, alpha_all = self._staged("z", z_all), self._staged("alpha", alpha_all)
         L.check(self.lib.gg_train_step(self.h, _ptr(x_real), C.byref(cond), _ptr(z_all), _ptr(alpha_all), n_critic,
                                        _ptr(self.losses), _stream()))
 
@@ -306,6 +339,9 @@ class Engine:
         us, by = (C.c_double * 4)(), (C.c_double * 4)()
         L.check(self.lib.gg_gp_profile(self.h, int(B), int(reps), us, by, _stream()))
         return [dict(kernel=n, us=us[i], bytes=by[i]) for i, n in enumerate(("gp_front_k", "gp_grad_k", "gp_coef_k", "gp_tail_k"))]
+
+    def optimizer_step(self, role):
+        return int(self.lib.gg_get_optimizer_step(self.h, role))
 
     def launch_count(self):
         return int(self.lib.gg_launch_count(self.h))

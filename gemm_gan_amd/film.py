@@ -74,7 +74,7 @@ class WGAN_GP(_m.WGAN_GP):
 
     def _text(self, text_embedding, B):
         text = text_embedding.to(self.device, torch.float32).reshape(B, 1, -1)
-        return text, torch.zeros(B, 1, dtype=torch.bool, device=self.device)
+        return text, self.engine.zeros(B, 1, dtype=torch.bool)
 
     def gradient_penalty(self, real_data, fake_data, text_embedding, patches, padding_mask):
         """F:322-345: the penalty value (0-d tensor, no autograd graph; alpha drawn by the same torch.rand call)."""

@@ -219,6 +219,11 @@ class WGAN_GP:
         self.gen = self.disc = None
         self.optimizer_disc = self.optimizer_gen = None
         self._noise_gen = None
+        # Opt-in (use_graph = True before the first step, or GG_GRAPH=1): gg_train_step replayed from a captured hipGraph once
+        # a resident batch has been seen twice (include/gemmgan.h).  Off by default: on ROCm 7.2 a replay halves the host's
+        # enqueue time (4.4 -> 2.2 ms per cfg3 step) but the GPU runs the graph's nodes SLOWER than the same kernels enqueued
+        # on three streams (38.5 vs 36.0 ms at cfg3, 2.03 vs 1.88 ms at configs[0]), and the host is not the bottleneck.
+        self.use_graph = os.environ.get("GG_GRAPH", "0") == "1"
         self.measure_comm = False
         self._comm_events = []
 
@@ -250,6 +255,7 @@ class WGAN_GP:
                      max_text_tokens=T, seed=self.seed, device=self.device, precision=self.precision,
                      variant=self._variant, clip_d=self._clip[0], clip_g=self._clip[1])
         eng._owner = self
+        eng.set_graph(self.use_graph)
         if old is not None:          # grow: keep parameters, gradients, optimiser state and step counters
             for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
                 for k in ("w", "g", "s1", "s2"):

@@ -71,9 +71,8 @@ class _NoCondNet(nn.Module):
 
 
 def _dummies(eng, B):
-    dev = eng.device
-    return (torch.zeros(B, 1, eng.cfg.patch_dims, device=dev), torch.zeros(B, 1, dtype=torch.bool, device=dev),
-            torch.zeros(B, 1, eng.cfg.text_dims, device=dev), torch.zeros(B, 1, dtype=torch.bool, device=dev))
+    mask = eng.zeros(B, 1, dtype=torch.bool)
+    return eng.zeros(B, 1, eng.cfg.patch_dims), mask, eng.zeros(B, 1, eng.cfg.text_dims), mask
 
 
 class generator_nocond(_NoCondNet):

@@ -182,6 +182,16 @@ int gg_set_side_streams(gg_engine* e, int on);
 int gg_train_step(gg_engine* e, const float* x_real, const gg_cond* c, const float* z_all,
                   const float* alpha_all, int n_critic, float* losses, void* stream);
 
+/* Captured step (hipGraph).  With gg_set_graph(e, 1) gg_train_step runs eagerly the first time it sees a set of argument
+ * pointers / shapes / hyper-parameters, captures its ~900 launches (three streams) into a graph the second time and
+ * replays the graph from then on: one hipGraphLaunch plus one 1-thread kernel that sets the device words the frozen
+ * kernel arguments cannot carry (dropout epoch, Adam step offset).  Up to 8 graphs are kept (least recently used
+ * evicted); callers whose buffers move every step simply stay eager.  Results are those of the eager path (same
+ * kernels, same order per stream); dropout masks differ between the two routes only in which random stream they draw.
+ * gg_graph_stats: graphs captured, replays, captures that failed (those signatures stay eager). */
+int gg_set_graph(gg_engine* e, int on);
+int gg_graph_stats(const gg_engine* e, int64_t* captures, int64_t* replays, int64_t* failures);
+
 /* ---- knobs mirrored from the reference trainer ------------------------------------------------------ */
 int gg_set_lr(gg_engine* e, int role, float lr);     /* optimizer.param_groups[i]['lr'] (R:651-657) */
 int gg_set_dropout(gg_engine* e, float p);            /* parity runs use 0 */
