@@ -84,9 +84,14 @@ def host_cores():
 def pmc_traffic(cls):
     """Launch-weighted mean HBM bytes per launch of the kernels in class `cls`, from the committed PMC summary
     (measured offline with rocprofv3 on this same command; bench.py cannot host the profiler itself)."""
-    try:
-        data = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-    except Exception:
+    data = None
+    for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):        # newest committed summary first
+        try:
+            data = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"]
+            break
+        except Exception:
+            pass
+    if data is None:
         return None
     # classes carry the kernels' own names: a full template name matches that instantiation, a bare name all of them
     want = cls.replace(" ", "")
@@ -339,13 +344,17 @@ def main():
                                "frac": round(frac_m if bound == "mfma" else frac_h, 4), "traffic": traffic,
                                "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                                "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes, "
-                                               "profiles/r01_pmc_traffic.json; algorithmic bytes per launch = "
+                                               "profiles/r02_pmc_traffic.json; algorithmic bytes per launch = "
                                                + str(round(dom["bytes"] / dom["launches"] / 1e6, 1)) + " MB",
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
                                "share_of_step": round(dom["ms"] / (dt * 1e3 * prof_steps / args.steps), 3),
                                "timed_steps_with_events": prof_steps,
-                               "note": "the kernel instantiation with the largest total time in a step with the engine's streams serialised "
-                                       "(classes carry the kernels' own template names, as rocprofv3 prints them); achieved / frac are "
+                               "note": "the kernel with the largest total time in a step with the engine's streams serialised, over ALL "
+                                       "heavy kernels - Linears, weight gradients, attention forward / dQ / dK|dV, LayerNorm backward, "
+                                       "small GEMMs per instantiation (classes carry the kernels' own names, as rocprofv3 prints "
+                                       "them); `bound` is the side of the ridge its algorithmic FLOP/byte falls on - the attention "
+                                       "kernels are in fact VALU-bound (exp2, dropout hash, conversions: ~25 ops per score), see "
+                                       "profiles/r02_pmc_mfma.json; achieved / frac are "
                                        "live over the timed region, where it shares the chip with the parameter-gradient / prefetch "
                                        "kernels of the side streams; `isolated` is the same kernel in the serialised warm-up step. "
                                        "In a rocprofv3 trace of the concurrent run the side-stream wgrad_kernel<true,false,false,false> "
@@ -357,9 +366,10 @@ def main():
                                                 "under their own classes below); every tensor of the chain is <= B*G*4 = "
                                                 f"{B * G * 4 / 1e6:.1f} MB, i.e. <= {B * G * 4 / 8e6:.2f} us at the HBM peak: launch-latency-"
                                                 "bound by construction at this minibatch",
-                               "all_gemm_classes_note": "one untimed warm-up step with event pairs on every class" if rows_all else
-                                                        "timed region",
-                               "all_gemm_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),
+                               "kernel_classes_note": ("one untimed warm-up step with event pairs on every class, streams serialised; "
+                                                       "algorithmic FLOPs and bytes per class (tensors once at their stored "
+                                                       "element sizes)") if rows_all else "timed region",
+                               "kernel_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),
                                                      "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                                                      "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in (rows_all or rows)]}
         if cpu is not None:

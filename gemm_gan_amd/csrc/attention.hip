@@ -1303,7 +1303,7 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
 }
 
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B) {
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B, hipEvent_t ev_mid) {
     const int qB = (int)(qkv_B > 0 ? qkv_B : N);
     GG_REQUIRE(flash_attn_supported(S, E, nh), "flash attention: unsupported shape");
     const int dh = E / nh;
@@ -1335,6 +1335,7 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
             GG_TRY(set_smem(&attn_bwd_dq_kernel<D, B>, sm));                                                                \
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
         }                                                                                                                   \
+        if (ev_mid) GG_CHECK_HIP(hipEventRecord(ev_mid, st));   /* profiling: splits the pair into its two kernels */ \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items, qB); \
     } while (0)
     if (io_bf16) {

@@ -212,6 +212,11 @@ struct gg_engine {
     size_t prof_next = 0;
     struct ProfAgg { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
     std::vector<ProfAgg> prof_agg;
+    // classes outside the fixed / Linear tables (attention, LayerNorm backward, FiLM-gradient reduction, small GEMMs per
+    // instantiation): registered by name on first use, ids 64 + index; taken with the full mask or when singled out
+    std::vector<std::string> named_cls;
+    bool prof_named_all = true;
+    int prof_named_one = -1;
     int str_cls[32] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
@@ -447,13 +452,51 @@ struct Ctx {
 
 inline long tiles_of(long M, long N) { return ((M + 127) / 128) * ((N + 127) / 128); }
 
+int named_class(gg_engine* e, const char* name) {
+    for (size_t i = 0; i < e->named_cls.size(); ++i)
+        if (e->named_cls[i] == name) return 64 + (int)i;
+    e->named_cls.emplace_back(name);
+    return 64 + (int)e->named_cls.size() - 1;
+}
+inline bool prof_wanted(const gg_engine* e, int cls) {
+    if (!e->prof_on) return false;
+    return cls < 64 ? ((e->prof_mask >> cls) & 1u) != 0 : (e->prof_named_all || e->prof_named_one == cls);
+}
+// event pair around a launch of a named class (the kernels taken this way run for >= tens of microseconds, or are counted
+// only in the serialised all-classes step)
+struct ProfScope {
+    Ctx& c;
+    bool on = false;
+    gg_engine::ProfRec r;
+    ProfScope(Ctx& c_, const char* name, double flops, double bytes) : c(c_) {
+        gg_engine* e = c.e;
+        if (!e->prof_on) return;
+        const int cls = named_class(e, name);
+        if (!prof_wanted(e, cls)) return;
+        if (e->prof_next + 2 > e->prof_pool.size())
+            for (int i = 0; i < 4096; ++i) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return;
+                e->prof_pool.push_back(ev);
+            }
+        r.cls = cls; r.flops = flops; r.bytes = bytes;
+        r.e0 = e->prof_pool[e->prof_next++];
+        r.e1 = e->prof_pool[e->prof_next++];
+        on = hipEventRecord(r.e0, c.st) == hipSuccess;
+    }
+    ~ProfScope() {
+        if (on && hipEventRecord(r.e1, c.st) == hipSuccess) c.e->prof_recs.push_back(r);
+    }
+};
+
 int run_gemm(Ctx& c, const GemmP& p) {
     gg_engine* e = c.e;
     e->launches++;
     const bool bf16 = e->precision == GG_PREC_BF16;
     const bool small = bf16 && e->small_on && gemm_small_wanted(p);
-    const int cls_ = small ? 11 : p.layA * 2 + p.layB + (bf16 ? 4 : 0);
-    if (!e->prof_on || !((e->prof_mask >> cls_) & 1u)) return small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
+    static const char* small_names[4] = {"gemm_small_kernel<0,0>", "gemm_small_kernel<0,1>", "gemm_small_kernel<1,0>", "gemm_small_kernel<1,1>"};
+    const int cls_ = !e->prof_on ? 0 : small ? named_class(e, small_names[p.layA * 2 + p.layB]) : p.layA * 2 + p.layB + (bf16 ? 4 : 0);
+    if (!prof_wanted(e, cls_)) return small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
     if (e->prof_next + 2 > e->prof_pool.size()) {
         for (int i = 0; i < 4096; ++i) {
             hipEvent_t ev;
@@ -469,7 +512,7 @@ int run_gemm(Ctx& c, const GemmP& p) {
     r.e0 = e->prof_pool[e->prof_next++];
     r.e1 = e->prof_pool[e->prof_next++];
     GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
-    if (small) r.cls = 11;
+    if (small) r.cls = cls_;
     int rc = small ? gemm_small(p, c.st) : (bf16 ? gemm_bf16(p, c.st) : gemm_f32(p, c.st));
     GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
     e->prof_recs.push_back(r);
@@ -772,7 +815,11 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         if (use_flash) {
-            KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st, share0 && l == 0 ? B : 0));
+            {   // algorithmic: packed QKV read once (B rows when layer 0 is shared by the replicas), context written once
+                const double tok = (double)RB * S, qtok = (share0 && l == 0 ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
+                ProfScope ps(c, "attn_fwd_kernel", 4.0 * tok * S * E, es * (3.0 * qtok * E + tok * E) + 4.0 * tok * nh);
+                KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st, share0 && l == 0 ? B : 0));
+            }
         } else {
             {   // scores[b,h] = scale * Q_h K_h^T, padded keys -> -inf
                 GemmP p;
@@ -1079,8 +1126,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         const float* x_in = l > 0 ? a.L[l - 1].x2 : (a.R > 1 && !a.share0 ? a.xrep : a.x0);
         // LN2
         GG_TRY(side_wait(c, 0));
-        KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
-                           dkey(e, a, n.role, l, 3), c.st, bst));
+        {   // reads dy and the saved pre-LN sum (fp32), writes dr (fp32) and the masked branch gradient (bf16 when stored so)
+            ProfScope ps(c, "ln_bwd_v4_k", 16.0 * RB * S * E, (double)RB * S * (E * (12.0 + (bst ? 2.0 : 4.0)) + 8.0));
+            KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
+                               dkey(e, a, n.role, l, 3), c.st, bst));
+        }
         // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))   (db2 = column sums of df: fused above)
         {
             Ctx cs = c;
@@ -1115,8 +1165,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         }
         // LN1
         GG_TRY(side_wait(c, 0));
-        KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
-                           dkey(e, a, n.role, l, 1), c.st, bst));
+        {
+            ProfScope ps(c, "ln_bwd_v4_k", 16.0 * RB * S * E, (double)RB * S * (E * (12.0 + (bst ? 2.0 : 4.0)) + 8.0));
+            KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
+                               dkey(e, a, n.role, l, 1), c.st, bst));
+        }
         // self attention out-proj   (d(out_proj.bias) fused above)
         {
             Ctx cs = c;
@@ -1134,7 +1187,26 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         const DropKey kA = dkey(e, a, n.role, l, 0);
         GG_TRY(side_wait(c, 2));
         if (a.flash) {
-            KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0));
+            {   // dQ kernel: reads QKV, O and dO (row dots), writes dQ; dK/dV kernel: reads QKV and dO, writes dK | dV
+                const double tok = (double)RB * S, qtok = (shared ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
+                hipEvent_t mid = nullptr;
+                if (e->prof_on && (prof_wanted(e, named_class(e, "attn_bwd_dq_kernel")) || prof_wanted(e, named_class(e, "attn_bwd_dkv_kernel")))) {
+                    if (e->prof_next + 1 > e->prof_pool.size())
+                        for (int i = 0; i < 4096; ++i) {
+                            hipEvent_t ev;
+                            GG_CHECK_HIP(hipEventCreate(&ev));
+                            e->prof_pool.push_back(ev);
+                        }
+                    mid = e->prof_pool[e->prof_next++];
+                }
+                ProfScope ps(c, "attn_bwd_dkv_kernel", 8.0 * tok * S * E, es * (3.0 * qtok * E + tok * E + 2.0 * tok * E) + 8.0 * tok * nh);
+                ProfScope pq(c, "attn_bwd_dq_kernel", 6.0 * tok * S * E, es * (3.0 * qtok * E + 2.0 * tok * E + tok * E) + 8.0 * tok * nh);
+                KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0, mid));
+                if (mid) {          // both scopes opened before the pair: dq = [pq.e0, mid], dkv = [mid, ps.e1]
+                    if (pq.on) { pq.r.e1 = mid; e->prof_recs.push_back(pq.r); pq.on = false; }
+                    if (ps.on) ps.r.e0 = mid;
+                }
+            }
             c.e->launches += 2;
         } else {
             const float* Pd = L.P;
@@ -1234,7 +1306,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         KL(k_fill(e->s_dgb, (long)B * 2 * Dp, 0.f, c.st));
         WgradFilmGrad f;
         f.W = w + n.pe_w; f.ldw = Dp; f.dgamma = e->s_dgb; f.dbeta = e->s_dgb + Dp; f.ld = 2 * Dp; f.tokens = P;
-        KL(wgrad(e->s_demb, E, 0, in->patches, Dp, 0, nullptr, 0, (long)B * P, E, Dp, c.st, nullptr, &f));
+        {
+            ProfScope ps(c, "wgrad_kernel<false,false,false,true>", 2.0 * B * P * E * (double)Dp, 4.0 * B * P * ((double)E + Dp) + 4.0 * E * Dp);
+            KL(wgrad(e->s_demb, E, 0, in->patches, Dp, 0, nullptr, 0, (long)B * P, E, Dp, c.st, nullptr, &f));
+        }
     } else {
         TlinP t;
         t.X = e->s_demb; t.ldx = E; t.M = (long)B * P; t.W = WTB(n, n.pe_w); t.ldw = E;
@@ -2097,14 +2172,33 @@ int gg_profile_enable(gg_engine* e, int on) {
     if (on < 0) { e->prof_on = false; return 0; }      // pause: no more event pairs, the records stay for gg_profile_collect
     e->prof_on = on != 0;
     e->prof_mask = on > 1 ? (unsigned)on >> 1 : 0xffffffffu;      // on = 1 | (class bit mask << 1) restricts the classes
+    e->prof_named_all = on == 1;
+    e->prof_named_one = -1;
     if (on) { e->prof_recs.clear(); e->prof_next = 0; }
+    return 0;
+}
+// event pairs for exactly one class, by the name gg_profile_read reported for it
+int gg_profile_enable_class(gg_engine* e, const char* name) {
+    GG_REQUIRE(e && name, "null argument");
+    e->prof_mask = 0; e->prof_named_all = false; e->prof_named_one = -1;
+    bool found = false;
+    for (size_t i = 0; i < e->named_cls.size() && !found; ++i)
+        if (e->named_cls[i] == name) { e->prof_named_one = 64 + (int)i; found = true; }
+    const size_t fixed = std::min<size_t>(32, 18 + (size_t)e->n_str_cls);       // prof_agg = fixed ids, Linear ids, named classes
+    for (size_t i = 0; i < e->prof_agg.size() && i < fixed && !found; ++i)
+        if (e->prof_agg[i].name == name) { e->prof_mask = 1u << i; found = true; }
+    GG_REQUIRE(found, "gg_profile_enable_class: unknown class (names come from gg_profile_read after a full collect)");
+    e->prof_on = true;
+    e->prof_recs.clear(); e->prof_next = 0;
     return 0;
 }
 int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;
     static const char* names[8] = {"gemm_f32_kernel<KC,KC>", "gemm_f32_kernel<KC,KS>", "gemm_f32_kernel<KS,KC>", "gemm_f32_kernel<KS,KS>",
                                    "gemm_bf16_kernel<KC,KC>", "gemm_bf16_kernel<KC,KS>", "gemm_bf16_kernel<KS,KC>", "gemm_bf16_kernel<KS,KS>"};
-    e->prof_agg.assign(18 + e->n_str_cls, gg_engine::ProfAgg());
+    const int named0 = 18 + e->n_str_cls;
+    e->prof_agg.assign(named0 + e->named_cls.size(), gg_engine::ProfAgg());
+    for (size_t i = 0; i < e->named_cls.size(); ++i) e->prof_agg[named0 + i].name = e->named_cls[i];
     for (int i = 0; i < e->n_str_cls; ++i) e->prof_agg[18 + i].name = e->str_cls_name[i];
     e->prof_agg[15].name = "wgrad_kernel<true,true,false,false>";
     e->prof_agg[16].name = "wgrad_kernel<false,false,false,false>";
@@ -2121,7 +2215,7 @@ int gg_profile_collect(gg_engine* e) {
         if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("hipEventSynchronize failed"); return -1; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { set_error("hipEventElapsedTime failed"); return -1; }
-        auto& a = e->prof_agg[r.cls];
+        auto& a = e->prof_agg[r.cls >= 64 ? named0 + (r.cls - 64) : r.cls];
         a.launches++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
     }
     e->prof_recs.clear();

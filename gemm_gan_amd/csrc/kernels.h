@@ -139,7 +139,7 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
                    DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0);
 // dctx [N,S,E] -> dqkv [N,S,3E] (fully overwritten); delta [N,nh,S] scratch
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
-                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0);
+                   int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0, hipEvent_t ev_mid = nullptr);
 
 // token-on-lane Linear (tlin.hip): Y[M,N] = epi(X[M,K] W[N,K]^T), bf16 MFMA, activations read once ---------------
 struct TlinP {

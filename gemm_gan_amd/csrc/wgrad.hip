@@ -25,7 +25,20 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-constexpr int WT = 1;                            // 32-row accumulator tiles per wave along n
+// (tools/wgrad_probe.hip rebuilds this file with other values; measured alternatives are listed in DESIGN.md section 3)
+#ifndef GG_WG_WT
+#define GG_WG_WT 1
+#endif
+#ifndef GG_WG_DEPTH
+#define GG_WG_DEPTH 4
+#endif
+#ifndef GG_WG_TARGET
+#define GG_WG_TARGET 256
+#endif
+#ifndef GG_WG_T22
+#define GG_WG_T22 0
+#endif
+constexpr int WT = GG_WG_WT;                     // 32-row accumulator tiles per wave along n
 constexpr int PN = 128 * WT, PK = 256, CT = 32;  // panel rows / cols, tokens per chunk
 constexpr int LDY = PN + 32, LDX = PK + 32;      // bf16 per LDS row: 144 dwords (16 mod 64) -> conflict-free transpose reads
 
@@ -82,6 +95,28 @@ struct Stager {
             }
         }
     }
+    // ---- fast path (whole chunks only): the chunk's first row is a UNIFORM address, the thread's pieces sit at chunk-local
+    // 32-bit byte offsets that never change (offsets(), once per kernel).  A load is then ONE instruction: no per-load 64-bit
+    // row * ld products, clamps, modulo or zeroing branches.  With the general path above the compiler emitted ~180
+    // instructions per load and - because an out-of-range piece was zeroed by overwriting the register the load targets -
+    // a wait for each load right after it was issued, which collapsed the DEPTH-deep prefetch ring to a depth of one:
+    // the kernel ran at memory LATENCY (measured: removing every MFMA changed its time by 5 %).  Out-of-range columns
+    // are blanked when the piece is written to LDS instead (store(.., zmask)).
+    static constexpr int ES = BF ? 2 : 4, EPP = BF ? 8 : 4;          // bytes per element, elements per piece
+    __device__ __forceinline__ static void offsets(unsigned (&voff)[NP], unsigned& zmask, long ld, int col0, int cols_valid, int tid) {
+        zmask = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+            const int cc = min(EPP * pc, cols_valid - EPP);
+            voff[i] = (unsigned)((row * ld + col0 + cc) * ES);
+            if (EPP * pc >= cols_valid) zmask |= 1u << i;
+        }
+    }
+    __device__ __forceinline__ void load_fast(const char* __restrict__ chunk_base, const unsigned (&voff)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) r[i] = *reinterpret_cast<const u32x4*>(chunk_base + voff[i]);
+    }
     // X' = gamma[sample] * X + beta[sample], sample = token / group: requested together with the chunk's rows
     __device__ __forceinline__ void load_film(const float* fg, const float* fb, long fld, int group, long tok0, long tok_end, int col0,
                                               int cols_valid, int tid) {
@@ -105,18 +140,18 @@ struct Stager {
             *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
         }
     }
-    __device__ __forceinline__ void store(__bf16* img, int ld, int tid) const {
+    __device__ __forceinline__ void store(__bf16* img, int ld, int tid, unsigned zmask = 0) const {
         if constexpr (BF) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
-                *reinterpret_cast<u32x4*>(img + row * ld + 8 * pc) = r[i];
+                *reinterpret_cast<u32x4*>(img + row * ld + 8 * pc) = ((zmask >> i) & 1u) ? u32x4{0u, 0u, 0u, 0u} : r[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
-                const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
+                const f32x4 v = ((zmask >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, r[i]);
                 u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
                 *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
             }
@@ -128,7 +163,7 @@ struct Stager {
 // weight matrix W [N,K] it belongs to:   dgamma[b,k] += sum_n W[n,k] C_b[n,k],   dbeta[b,k] += sum_n W[n,k] s_b[n],
 // s_b[n] = sum_tokens dY_b[token,n]  - the gradients of a FiLM modulation X' = gamma_b * X + beta_b that sits in front of
 // the Linear W, without materialising d(X') = dY W  (dgamma = sum_tokens dX' * X, dbeta = sum_tokens dX').
-template <bool YB, bool XB, bool FILM, bool FGRAD>
+template <bool YB, bool XB, bool FILM, bool FGRAD, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
                                                     float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
                                                     WgradFilmGrad fg, float* __restrict__ dbias, long x_mod) {
@@ -158,21 +193,110 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     float ssum = 0.f;                                   // sum over tokens of dY[token, row 32*wave + c] (this lane's half of every 16)
     const bool do_bias = dbias != nullptr && k0 == 0;   // bias gradient = column sums of dY: once per row panel
 
-    f32x16 acc[WT][8];
+    // Wave tiling of the panel.  4 x 1: wave w owns rows [32w, 32w+32) x all 256 columns (1 A fragment, 8 B fragments per
+    // 16-token step: every wave reads the WHOLE X chunk from LDS).  2 x 2 (T22): wave (wn, wk) owns 64 rows x 128 columns
+    // (2 A + 4 B fragments): a third fewer LDS fragment reads for the same 8 MFMAs - the LDS read stream is what bounds the
+    // kernel once its loads are prefetched.  The FiLM-gradient epilogue is written for the 4 x 1 map.
+    constexpr bool T22 = GG_WG_T22 && !FGRAD && WT == 1;
+    constexpr int TA = T22 ? 2 : WT, TB = T22 ? 4 : 8;
+    const int nb = T22 ? (wave >> 1) * 64 : wave * (32 * WT), kb = T22 ? (wave & 1) * 128 : 0;
+    float ssum2 = 0.f;                                  // T22: column sums of the wave's second 32-row tile
+    f32x16 acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < WT; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < TB; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     // Token chunks travel HBM -> registers -> LDS through a ring of DEPTH register stages: chunk r + DEPTH is
     // requested when chunk r is multiplied and written to LDS DEPTH - 1 chunks later, so an HBM round trip is
     // covered by DEPTH - 1 MFMA passes (one pass = 32 MFMAs, far shorter than the memory latency on its own).
-    constexpr int DEPTH = 4;
+#ifndef GG_WG_DEPTH_F32Y
+#define GG_WG_DEPTH_F32Y 3
+#endif
+#ifndef GG_WG_DEPTH_FILM
+#define GG_WG_DEPTH_FILM 2
+#endif
+    // ring depth by register budget (the branch-free loader keeps every stage live): a stage is 40 registers with bf16 dY,
+    // 48 with fp32 dY, 64 with FiLM operands on top
+    constexpr int DEPTH = !FAST ? GG_WG_DEPTH : FILM ? GG_WG_DEPTH_FILM : !YB ? GG_WG_DEPTH_F32Y : GG_WG_DEPTH;
     Stager<YB, PN> sy[DEPTH];
     Stager<XB, PK> sx[DEPTH];
     const long nch = c_end - c_beg;
+#ifndef GG_WG_ABL
+#define GG_WG_ABL 0          // tools/wgrad_probe.hip ablations: 1 = no fragment reads / MFMAs, 2 = no LDS writes of X
+#endif
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < ((GG_WG_ABL & 1) ? 0 : 2); ++s2) {
+            bf16x8 af[TA];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) af[a] = frag_tr(Ysb(buf), LDY, nb + a * 32, s2, lane);
+            if (FGRAD || do_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)af[0][j] << 16);
+                if constexpr (T22) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ssum2 += __builtin_bit_cast(float, (unsigned)(unsigned short)af[1][j] << 16);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const bf16x8 bf = frag_tr(Xsb(buf), LDX, kb + b * 32, s2, lane);
+#pragma unroll
+                for (int a = 0; a < TA; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+    if constexpr (FAST) {
+        // whole chunks only (the host checks M % CT == 0 and x_mod % CT == 0): branch-free issue, see Stager::load_fast.
+        // Issues past the last chunk repeat it (their data is written to LDS but never multiplied), so the loop body has
+        // no conditional around a load and the compiler's wait counts are those of the steady state.
+        unsigned voy[Stager<YB, PN>::NP], vox[Stager<XB, PK>::NP], zmy, zmx;
+        Stager<YB, PN>::offsets(voy, zmy, ldy, n0, nvalid, tid);
+        Stager<XB, PK>::offsets(vox, zmx, ldx, k0, kvalid, tid);
+        const long ystep = (long)CT * ldy * Stager<YB, PN>::ES;
+        const char* ycur = reinterpret_cast<const char*>(dY) + c_beg * ystep;
+        long xr = x_mod > 0 ? (c_beg * CT) % x_mod : c_beg * CT;          // row of X the next issue starts at
+        long issued = 0;
+        auto issue = [&](Stager<YB, PN>& ys, Stager<XB, PK>& xs) {
+            ys.load_fast(ycur, voy);
+            xs.load_fast(reinterpret_cast<const char*>(X) + xr * ldx * Stager<XB, PK>::ES, vox);
+            if constexpr (FILM) xs.load_film(film.g, film.b, film.ld, film.group, (c_beg + min(issued, nch - 1)) * CT, M, k0, kvalid, tid);
+            if (issued + 1 < nch) {
+                ycur += ystep;
+                xr += CT;
+                if (x_mod > 0 && xr >= x_mod) xr -= x_mod;
+            }
+            ++issued;
+        };
+        auto to_lds = [&](int st, int buf) {
+            sy[st].store(Ysb(buf), LDY, tid, zmy);
+            if constexpr (GG_WG_ABL & 2) {
+                u32x4 t = sx[st].r[0];
+                for (int i = 1; i < Stager<XB, PK>::NP; ++i) t |= sx[st].r[i];
+                if (t[0] == 0x12345678u) sx[st].store(Xsb(buf), LDX, tid);
+            } else if constexpr (FILM) sx[st].store_film(Xsb(buf), LDX, tid);
+            else sx[st].store(Xsb(buf), LDX, tid);
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(sy[d], sx[d]);
+        to_lds(0, 0);
+        __syncthreads();
+        for (long r0 = 0; r0 < nch; r0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const long r = r0 + u;
+                if (r >= nch) break;
+                const int buf = (int)(r & 1);
+                issue(sy[u], sx[u]);                       // chunk r + DEPTH
+                multiply(buf);
+                to_lds((u + 1) % DEPTH, buf ^ 1);          // chunk r + 1
+                __syncthreads();
+            }
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
         if (d < nch) {
@@ -196,22 +320,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                     sx[u].load(X, ldx, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid, false, x_mod);
                     if constexpr (FILM) sx[u].load_film(film.g, film.b, film.ld, film.group, (c_beg + r + DEPTH) * CT, M, k0, kvalid, tid);
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 af[WT];
-#pragma unroll
-                    for (int a = 0; a < WT; ++a) af[a] = frag_tr(Ysb(buf), LDY, wave * (32 * WT) + a * 32, s2, lane);
-                    if (FGRAD || do_bias) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)af[0][j] << 16);
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const bf16x8 bf = frag_tr(Xsb(buf), LDX, b * 32, s2, lane);
-#pragma unroll
-                        for (int a = 0; a < WT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
-                    }
-                }
+                multiply(buf);
                 if (r + 1 < nch) {
                     sy[(u + 1) % DEPTH].store(Ysb(buf ^ 1), LDY, tid);
                     if constexpr (FILM) sx[(u + 1) % DEPTH].store_film(Xsb(buf ^ 1), LDX, tid);
@@ -220,6 +329,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 __syncthreads();
             }
         }
+    }
     }
     if constexpr (FGRAD) {
         // s of the wave's 32 rows -> LDS (the staging buffers are free after the last barrier), then per register row
@@ -255,20 +365,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
         return;
     }
     if (do_bias) {
-        ssum += __shfl_xor(ssum, 32, 64);
-        if (h == 0 && wave * 32 + c < nvalid) atomicAdd(dbias + n0 + wave * 32 + c, ssum);
+        if constexpr (T22) {
+            if ((wave & 1) == 0) {                       // both column halves hold the same dY rows: one of them adds
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssum2 += __shfl_xor(ssum2, 32, 64);
+                if (h == 0 && nb + c < nvalid) atomicAdd(dbias + n0 + nb + c, ssum);
+                if (h == 0 && nb + 32 + c < nvalid) atomicAdd(dbias + n0 + nb + 32 + c, ssum2);
+            }
+        } else {
+            ssum += __shfl_xor(ssum, 32, 64);
+            if (h == 0 && wave * 32 + c < nvalid) atomicAdd(dbias + n0 + wave * 32 + c, ssum);
+        }
     }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
-    float* wbase = dW + (long)(n0 + wave * (32 * WT) + 4 * h) * ldw + k0 + c;
+    float* wbase = dW + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
 #pragma unroll
-    for (int a = 0; a < WT; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b * 32 + c < kvalid) {
+        for (int b = 0; b < TB; ++b) {
+            if (kb + b * 32 + c < kvalid) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int rr = a * 32 + (i & 3) + 8 * (i >> 2);       // row inside the wave's 64-row slice (minus 4h)
-                    if (wave * (32 * WT) + 4 * h + rr < nvalid) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
+                    const int rr = a * 32 + (i & 3) + 8 * (i >> 2);       // row inside the wave's slice (minus 4h)
+                    if (nb + 4 * h + rr < nvalid) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one tile's accumulators at a time: no mass copy-out (spills)
@@ -299,21 +418,30 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     const long chunks = (M + CT - 1) / CT;
     // one workgroup per CU (256 accumulator registers => one wave per SIMD): panels x splits ~ 256; every extra
     // split costs a 256 KB atomic panel add, every missing one idles a CU
-    int splits = (int)std::max<long>(1, std::min<long>(chunks / 8, (256 + panels - 1) / panels));
+    int splits = (int)std::max<long>(1, std::min<long>(chunks / 8, (GG_WG_TARGET + panels - 1) / panels));
     if (splits >= 8) splits = splits / 8 * 8;            // whole groups of 8 splits (one per XCD), never more than 256 workgroups
     if (fgrad.W) splits = (int)(M / fgrad.tokens);      // one split per sample
     const int split_groups = (splits + 7) / 8;
     const dim3 grid((unsigned)(panels * split_groups * 8));
     constexpr int SMEM = 2 * CT * (LDY + LDX) * 2;
-#define GG_WG(YB, XB, FL, FG)                                                                                              \
+    // whole chunks and (for replica-shared inputs) a period of whole chunks: the branch-free loader; anything else (a ragged
+    // last chunk) the general one
+    static const bool no_fast = getenv("GG_WGRAD_GENERAL") != nullptr;
+    const bool fast = !no_fast && M % CT == 0 && (x_mod == 0 || x_mod % CT == 0) && ldy * 4 * CT < (1L << 31) / 1 && ldx * 4 * CT < (1L << 31);
+#define GG_WG1(YB, XB, FL, FG, FA)                                                                                         \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL, FG>),             \
+            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL, FG, FA>),         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG, FA>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
+    } while (0)
+#define GG_WG(YB, XB, FL, FG)                  \
+    do {                                       \
+        if (fast) GG_WG1(YB, XB, FL, FG, true); \
+        else GG_WG1(YB, XB, FL, FG, false);    \
     } while (0)
     if (fgrad.W) {
         GG_WG(false, false, false, true);
@@ -325,6 +453,7 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     else if (x_bf16) GG_WG(false, true, false, false);
     else GG_WG(false, false, false, false);
 #undef GG_WG
+#undef GG_WG1
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }

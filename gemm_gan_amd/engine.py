@@ -305,13 +305,11 @@ class Engine:
 
     def profile(self, on: bool, classes=None):
         """HIP-event pair around every GEMM-class launch (classes=None) or only around the named classes."""
-        arg = int(bool(on))
         if on and classes:
-            mask = 0
-            ids = getattr(self, "_prof_ids", {})         # names seen by the last profile_collect (stream-Linear classes are dynamic)
-            for c in classes:
-                mask |= 1 << (ids[c] if c in ids else self.PROFILE_CLASSES.index(c))
-            arg = 1 | (mask << 1)
+            assert len(classes) == 1, "one class at a time (names as profile_collect reports them)"
+            L.check(self.lib.gg_profile_enable_class(self.h, classes[0].encode()))
+            return
+        arg = int(bool(on))
         L.check(self.lib.gg_profile_enable(self.h, arg))
 
     def profile_pause(self):

@@ -229,6 +229,7 @@ int gg_debug_buffer_is_bf16(gg_engine* e, const char* name);   /* 1 if that buff
  * "gemm_f32<A-layout,B-layout>") launches, total milliseconds, algorithmic FLOPs (2*M*N*K*batch) and
  * algorithmic bytes ((M*K + K*N + M*N)*4*batch).  gg_profile_read returns row i of the aggregate. */
 int gg_profile_enable(gg_engine* e, int on);
+int gg_profile_enable_class(gg_engine* e, const char* name);   /* event pairs for ONE class, by its gg_profile_read name */
 int gg_profile_collect(gg_engine* e);            /* returns number of classes, <0 on error */
 int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* launches, double* ms,
                     double* flops, double* bytes);

@@ -1,5 +1,5 @@
-"""profiles/r01_pmc_traffic.json from the two passes of tools/pmc_traffic.sh.
-usage: python tools/pmc_traffic_summary.py gpurun_out/pmc_fetch/*/*_counter_collection.csv gpurun_out/pmc_write/*/*_counter_collection.csv"""
+"""profiles/rNN_pmc_traffic.json from the two passes of tools/pmc_traffic.sh.
+usage: python tools/pmc_traffic_summary.py gpurun_out/pmc_fetch/*/*_counter_collection.csv gpurun_out/pmc_write/*/*_counter_collection.csv [out.json]"""
 import csv, sys, json, re, collections
 acc = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for f in sys.argv[1:3]:
@@ -11,7 +11,7 @@ for f in sys.argv[1:3]:
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, v in acc.items():
-    if not v["FETCH_SIZE"] or not v["WRITE_SIZE"] or not (k.startswith("tlin") or k.startswith("attn") or k.startswith("wgrad") or "ln_bwd" in k or k.startswith("sqx")):
+    if not v["FETCH_SIZE"] or not v["WRITE_SIZE"] or not (k.startswith("tlin") or k.startswith("wst") or k.startswith("gp_") or k.startswith("attn") or k.startswith("wgrad") or "ln_bwd" in k or k.startswith("sqx")):
         continue
     fb = 2.0 * 1024 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])      # gfx950: FETCH_SIZE counts half of a wide coalesced read
     wb = 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
@@ -20,6 +20,6 @@ doc = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
                  "--warmup 1`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE halves wide coalesced reads, "
                  "MI355X_MICROARCH.md HBM section); launch-weighted means per kernel instantiation",
        "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["launches"] * kv[1]["hbm_bytes_per_launch"]))}
-json.dump(doc, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+json.dump(doc, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_pmc_traffic.json", "w"), indent=1)
 for k, v in doc["kernels"].items():
     print(f"{k[:56]:56s} launches {v['launches']:4d}  {v['hbm_bytes_per_launch']/1e6:8.1f} MB/launch")
