@@ -94,6 +94,8 @@ SYMBOLS = {
     "gg_test_gemm_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
                                      C.c_int, C.c_void_p]),
+    "gg_test_gemm_bf16_stored": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                           C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gg_test_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
                                     C.c_int, C.c_void_p]),

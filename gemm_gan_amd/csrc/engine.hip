@@ -2306,6 +2306,15 @@ int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, i
     return gemm_small(p, (hipStream_t)stream);
 }
 
+/* K-strided operands stored as bf16 (the weight-gradient products of bf16-stored branch gradients / activations) */
+int gg_test_gemm_bf16_stored(const void* A, const void* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                             int a_bf16, int b_bf16, int splitk, void* stream) {
+    GemmP p;
+    p.A = reinterpret_cast<const float*>(A); p.B = reinterpret_cast<const float*>(B); p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = a_bf16; p.b_bf16 = b_bf16; p.splitk = splitk;
+    return gemm_bf16(p, (hipStream_t)stream);
+}
+
 int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                       int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
                       void* stream) {

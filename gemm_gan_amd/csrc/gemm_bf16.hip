@@ -39,24 +39,51 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // bf16-stored K-strided operand (weight-gradient products of bf16 branch gradients / activations): 8-byte loads of
 // 4 adjacent rows at one k, expanded exactly to fp32 so the staging below is shared with the fp32 path
-__device__ __forceinline__ void load_tile_ks_bf16(const __bf16* __restrict__ base, long ld, int rows_total, int row0, int k0,
-                                                   int kend, f32x4 (&r)[8], int tid) {
+// All loaders return a bit mask of the slots that lie outside the operand.  The aligned paths issue their 8 loads
+// UNCONDITIONALLY from clamped addresses and leave blanking (and the bf16 expansion) to finish_tile(), which runs after the
+// MFMA block of the current tile: a guard around each load made the compiler wait for every load where it was issued,
+// which serialised the loads and put them in front of the MFMAs they were meant to hide behind.
+__device__ __forceinline__ unsigned load_tile_ks_bf16(const __bf16* __restrict__ base, long ld, int rows_total, int row0, int k0,
+                                                       int kend, f32x4 (&r)[8], int tid) {
+    unsigned blank = 0;
+    const int gr = row0 + 4 * (tid & 31);
+    const __bf16* src = base + (gr < rows_total ? gr : 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int gk = k0 + 8 * (tid >> 5) + i, gr = row0 + 4 * (tid & 31);
-        if (gk < kend && gr < rows_total) {
-            const u32x2 w = *reinterpret_cast<const u32x2*>(base + (long)gk * ld + gr);
-            v = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
-                      __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
-        }
-        r[i] = v;
+        const int gk = k0 + 8 * (tid >> 5) + i;
+        const u32x2 w = *reinterpret_cast<const u32x2*>(src + (long)min(gk, kend - 1) * ld);
+        r[i] = __builtin_bit_cast(f32x4, u32x4{w[0], w[1], 0u, 0u});      // raw bits: expanded by finish_tile
+        if (!(gk < kend && gr < rows_total)) blank |= 1u << i;
     }
+    return blank;
 }
 
 template <int LAY>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, long ld, int rows_total, int row0, int k0,
-                                          int kend, bool vec, f32x4 (&r)[8], int tid) {
+__device__ __forceinline__ unsigned load_tile(const float* __restrict__ base, long ld, int rows_total, int row0, int k0,
+                                              int kend, bool vec, f32x4 (&r)[8], int tid) {
+    unsigned blank = 0;
+    if (vec) {
+        if (LAY == LAY_KC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = tid + NTHREADS * (i >> 1);
+                const int row = f >> 3, c8 = f & 7;
+                const int gr = row0 + row, gk = k0 + 8 * c8 + 4 * (i & 1);
+                r[i] = *reinterpret_cast<const f32x4*>(base + (long)min(gr, rows_total - 1) * ld + min(gk, kend - 4));
+                if (!(gr < rows_total && gk < kend)) blank |= 1u << i;
+            }
+        } else {
+            const int gr = row0 + 4 * (tid & 31);
+            const float* src = base + min(gr, rows_total - 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gk = k0 + 8 * (tid >> 5) + i;
+                r[i] = *reinterpret_cast<const f32x4*>(src + (long)min(gk, kend - 1) * ld);
+                if (!(gk < kend && gr < rows_total)) blank |= 1u << i;
+            }
+        }
+        return blank;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -66,28 +93,35 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
             const int gr = row0 + row, gk = k0 + 8 * c8 + 4 * (i & 1);
             if (gr < rows_total) {
                 const float* src = base + (long)gr * ld + gk;
-                if (vec) {
-                    if (gk < kend) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (gk + j < kend) v[j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (gk + j < kend) v[j] = src[j];
             }
         } else {
             const int gk = k0 + 8 * (tid >> 5) + i, gr = row0 + 4 * (tid & 31);
             if (gk < kend) {
                 const float* src = base + (long)gk * ld + gr;
-                if (vec) {
-                    if (gr < rows_total) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (gr + j < rows_total) v[j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (gr + j < rows_total) v[j] = src[j];
             }
         }
         r[i] = v;
+    }
+    return 0;
+}
+// blank the out-of-range slots; RAW16: expand the two dwords of 4 bf16 values to fp32 first
+template <bool RAW16>
+__device__ __forceinline__ void finish_tile(f32x4 (&r)[8], unsigned blank) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (RAW16) {
+            const u32x4 u = __builtin_bit_cast(u32x4, r[i]);
+            const unsigned w0 = u[0], w1 = u[1];
+            r[i] = f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                         __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+        }
+        if ((blank >> i) & 1u) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -178,13 +212,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    auto loadA = [&](int k0, f32x4 (&ra)[8]) {
-        if constexpr (AB) load_tile_ks_bf16(Ab, p.lda, p.M, m0, k0, kend, ra, tid);
-        else load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
+    auto loadA = [&](int k0, f32x4 (&ra)[8]) -> unsigned {
+        if constexpr (AB) return load_tile_ks_bf16(Ab, p.lda, p.M, m0, k0, kend, ra, tid);
+        else return load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
     };
-    auto loadB = [&](int k0, f32x4 (&rb)[8]) {
-        if constexpr (BB) load_tile_ks_bf16(Bb, p.ldb, p.N, n0, k0, kend, rb, tid);
-        else load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
+    auto loadB = [&](int k0, f32x4 (&rb)[8]) -> unsigned {
+        if constexpr (BB) return load_tile_ks_bf16(Bb, p.ldb, p.N, n0, k0, kend, rb, tid);
+        else return load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
     };
 
     f32x16 acc[2][2];
@@ -196,10 +230,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
     f32x4 ra[8], rb[8];
+    unsigned ba = 0, bb = 0;
     if (nkt > 0) {
-        loadA(kbeg, ra);
+        ba = loadA(kbeg, ra);
+        bb = loadB(kbeg, rb);
+        finish_tile<AB>(ra, ba);
         if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, kbeg, kend, fl.vecFilm, ra, tid);
-        loadB(kbeg, rb);
+        finish_tile<BB>(rb, bb);
         store_tile<LA>(As, ra, tid);
         store_tile<LB>(Bs, rb, tid);
     }
@@ -210,9 +247,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
         const bool more = (kt + 1 < nkt);
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
-            loadA(k0, ra);
-            if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, k0, kend, fl.vecFilm, ra, tid);
-            loadB(k0, rb);
+            ba = loadA(k0, ra);
+            bb = loadB(k0, rb);
         }
         const __bf16* at = As + cur * TILE_ELEMS;
         const __bf16* bt = Bs + cur * TILE_ELEMS;
@@ -232,6 +268,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmP p, cons
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
         if (more) {
+            finish_tile<AB>(ra, ba);
+            if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, kbeg + (kt + 1) * BK, kend, fl.vecFilm, ra, tid);
+            finish_tile<BB>(rb, bb);
             store_tile<LA>(As + (cur ^ 1) * TILE_ELEMS, ra, tid);
             store_tile<LB>(Bs + (cur ^ 1) * TILE_ELEMS, rb, tid);
         }

@@ -32,9 +32,31 @@ struct Flags {
 };
 
 // ---- global -> register staging of one 128 x 32 operand tile (4 float4 per thread) ---------------
+// Returns a bit mask of the slots outside the operand.  The aligned path loads UNCONDITIONALLY from clamped addresses and
+// the caller blanks those slots (blank_tile) after the MFMA block of the current tile - see gemm_bf16.hip: a guard
+// around each load made the compiler wait for every load where it was issued.
 template <int LAY>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, long ld, int rows_total, int row0,
-                                          int k0, int kend, bool vec, f32x4 (&r)[4], int tid) {
+__device__ __forceinline__ unsigned load_tile(const float* __restrict__ base, long ld, int rows_total, int row0,
+                                              int k0, int kend, bool vec, f32x4 (&r)[4], int tid) {
+    if (vec) {
+        unsigned blank = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + NTHREADS * i;
+            if (LAY == LAY_KC) {
+                const int row = f >> 3, c4 = f & 7;
+                const int gr = row0 + row, gk = k0 + 4 * c4;
+                r[i] = *reinterpret_cast<const f32x4*>(base + (long)min(gr, rows_total - 1) * ld + min(gk, kend - 4));
+                if (!(gr < rows_total && gk < kend)) blank |= 1u << i;
+            } else {
+                const int k = f >> 5, c4 = f & 31;
+                const int gk = k0 + k, gr = row0 + 4 * c4;
+                r[i] = *reinterpret_cast<const f32x4*>(base + (long)min(gk, kend - 1) * ld + min(gr, rows_total - 4));
+                if (!(gk < kend && gr < rows_total)) blank |= 1u << i;
+            }
+        }
+        return blank;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + NTHREADS * i;
@@ -44,30 +66,28 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
             const int gr = row0 + row, gk = k0 + 4 * c4;
             if (gr < rows_total) {
                 const float* src = base + (long)gr * ld + gk;
-                if (vec) {
-                    if (gk < kend) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (gk + j < kend) v[j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (gk + j < kend) v[j] = src[j];
             }
         } else {
             const int k = f >> 5, c4 = f & 31;
             const int gk = k0 + k, gr = row0 + 4 * c4;
             if (gk < kend) {
                 const float* src = base + (long)gk * ld + gr;
-                if (vec) {
-                    if (gr < rows_total) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (gr + j < rows_total) v[j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (gr + j < rows_total) v[j] = src[j];
             }
         }
         r[i] = v;
     }
+    return 0;
+}
+__device__ __forceinline__ void blank_tile(f32x4 (&r)[4], unsigned blank) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((blank >> i) & 1u) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // FiLM on the A operand (LAY_KC):  a' = gamma[g][k] * a + beta[g][k],  g = m / group
@@ -170,10 +190,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p, const
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
     f32x4 ra[4], rb[4];
+    unsigned ba = 0, bb = 0;
     if (nkt > 0) {
-        load_tile<LA>(A, p.lda, p.M, m0, kbeg, kend, fl.vecA, ra, tid);
+        ba = load_tile<LA>(A, p.lda, p.M, m0, kbeg, kend, fl.vecA, ra, tid);
+        bb = load_tile<LB>(B, p.ldb, p.N, n0, kbeg, kend, fl.vecB, rb, tid);
+        blank_tile(ra, ba);
         if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, kbeg, kend, fl.vecFilm, ra, tid);
-        load_tile<LB>(B, p.ldb, p.N, n0, kbeg, kend, fl.vecB, rb, tid);
+        blank_tile(rb, bb);
         store_tile<LA>(As, ra, tid);
         store_tile<LB>(Bs, rb, tid);
     }
@@ -184,9 +207,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p, const
         const bool more = (kt + 1 < nkt);
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
-            if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, k0, kend, fl.vecFilm, ra, tid);
-            load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
+            ba = load_tile<LA>(A, p.lda, p.M, m0, k0, kend, fl.vecA, ra, tid);
+            bb = load_tile<LB>(B, p.ldb, p.N, n0, k0, kend, fl.vecB, rb, tid);
         }
         const float* at = As + cur * TILE_FLOATS;
         const float* bt = Bs + cur * TILE_FLOATS;
@@ -206,6 +228,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p, const
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
         }
         if (more) {
+            blank_tile(ra, ba);
+            if (LA == LAY_KC && p.film_gamma) film_tile(p, m0, kbeg + (kt + 1) * BK, kend, fl.vecFilm, ra, tid);
+            blank_tile(rb, bb);
             store_tile<LA>(As + (cur ^ 1) * TILE_FLOATS, ra, tid);
             store_tile<LB>(Bs + (cur ^ 1) * TILE_FLOATS, rb, tid);
         }

@@ -213,6 +213,8 @@ int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
 int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                        float slope, int accumulate, void* stream);
+int gg_test_gemm_bf16_stored(const void* A, const void* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                             int64_t ldc, int a_bf16, int b_bf16, int splitk, void* stream);   /* [K,M] / [K,N] operands, bf16-stored */
 int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                       int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                       float slope, int accumulate, void* stream);

@@ -129,3 +129,25 @@ def test_gemm_small_layouts_exact_integer(layA, layB):
     ck.check("alpha+bias+accumulate+leaky", run_gemm(A, B, M, N, K, layA, layB, alpha=2.0, bias=bias, act=1, slope=0.5, C0=C0,
                                                      accumulate=1, kernel="gg_test_gemm_small"), want.float())
     ck.done()
+
+
+@pytest.mark.parametrize("a_bf16,b_bf16", [(1, 1), (1, 0), (0, 1)])
+def test_gemm_bf16_stored_operands_exact_integer(a_bf16, b_bf16):
+    """dW = dY^T X with K-strided operands stored as bf16 (engine: weight gradients of bf16-stored branch gradients when the
+    reduction is too short for the token-reduction kernel): ragged reduction length, split-K, ragged tiles."""
+    lib = L.load()
+    ck = Checker(f"gemm bf16-stored operands a={a_bf16} b={b_bf16}", 0.0, metric="max")
+    for (M, N, K, sk) in [(128, 128, 64, 1), (768, 256, 1542, 4), (256, 512, 771, 3), (72, 40, 130, 1), (512, 256, 1028, 16)]:
+        g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+        Am = torch.randint(-3, 4, (K, M), generator=g).float() + (torch.arange(M)[None, :] % 5 == 0).float()
+        Bm = torch.randint(-3, 4, (K, N), generator=g).float() + (torch.arange(N)[None, :] % 7 == 0).float() * 2
+        A = (Am.bfloat16() if a_bf16 else Am).contiguous().cuda()
+        B = (Bm.bfloat16() if b_bf16 else Bm).contiguous().cuda()
+        out = torch.zeros(M, N, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.gg_test_gemm_bf16_stored(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(out.data_ptr()), M, N, K,
+                                          M, N, N, a_bf16, b_bf16, sk, st)
+        assert rc == 0, lib.gg_last_error()
+        torch.cuda.synchronize()
+        ck.check(f"{M}x{N}x{K} sk{sk}", out, (Am.double().t() @ Bm.double()).float())
+    ck.done()

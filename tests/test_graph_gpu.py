@@ -36,7 +36,9 @@ def test_graph_route_equals_eager_route(case, precision, optimizer):
     """Lock-step: before every step the graph engine takes the eager engine's parameters and optimiser state (same
     addresses, so the captured graph stays valid), then both run the step on the same inputs.  That keeps the comparison a
     ONE-step one - RMSprop / Adam turn the rounding noise of a near-zero gradient into a full +-lr step, so free-running
-    trajectories of two bit-different but equally right runs drift apart (tests/test_numpy_oracle.py measures it)."""
+    trajectories of two bit-different but equally right runs drift apart (tests/test_numpy_oracle.py measures it).  In bf16
+    mode up to ~10 % of the generator's entries (gene-output weights whose gradient is rounding noise) take such a step in
+    either direction under Adam, in two eager runs as much as between the routes: the gate allows 15 %."""
     c = CASES[case]
     cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
     torch.manual_seed(11)
@@ -62,7 +64,7 @@ def test_graph_route_equals_eager_route(case, precision, optimizer):
         ck.check(f"step {s}: losses", graph.losses[:4], eager.losses[:4])
         for r, name, k in ((L.ROLE_CRITIC, "critic", n), (L.ROLE_GENERATOR, "generator", 1)):
             ck.check_post(f"step {s}: {name} parameters", graph.flat[r]["w"], eager.flat[r]["w"].cpu().numpy(), init[r].cpu().numpy(),
-                          optimizer, lr[r], k if optimizer == "rms_prop" else s * k + k, rtol=1e-3 if f32 else 5e-2, share=0.03 if f32 else 0.08)
+                          optimizer, lr[r], k if optimizer == "rms_prop" else s * k + k, rtol=1e-3 if f32 else 5e-2, share=0.03 if f32 else 0.15)
     st = graph.graph_stats()
     diag(f"   {st}, {graph.launch_count()} launches per step")
     assert st == {"captures": 1, "replays": steps - 2, "failures": 0}, st
