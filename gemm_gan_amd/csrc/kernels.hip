@@ -577,15 +577,24 @@ __global__ __launch_bounds__(TPB) void colsum_k(const float* X, const float* ref
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (c0 < N) {
         if (vec && c0 + 3 < N) {
-            for (long r = r0 + rl; r < r1; r += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ld + c0);
-                if (ref) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(ref + r * ld + c0);
+            // 8 rows per thread at a time, all loads issued before the first add (clamped rows, masked adds): a load - add
+            // loop costs one memory round trip per row, and the short matrices this kernel mostly sees are 8 rows per thread
+            for (long rb = r0 + rl; rb < r1; rb += 32) {
+                f32x4 v[8], q[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s[j] += v[j] * (q[j] > 0.f ? 1.f : slope);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(X + min(rb + 4 * u, rows - 1) * ld + c0);
+                if (ref) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const f32x4*>(ref + min(rb + 4 * u, rows - 1) * ld + c0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] += rb + 4 * u < r1 ? v[u][j] * (q[u][j] > 0.f ? 1.f : slope) : 0.f;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s[j] += v[j];
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] += rb + 4 * u < r1 ? v[u][j] : 0.f;
                 }
             }
         } else {
