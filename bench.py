@@ -98,7 +98,8 @@ def pmc_traffic(cls):
     n = b = 0.0
     for k, v in data.items():
         kk = k.replace(" ", "").replace("gg::", "")
-        if kk == want or ("<" not in want and kk.split("<")[0] == want):
+        # (an instantiation may carry trailing template arguments the class name omits, e.g. wgrad's loader flag)
+        if kk == want or ("<" not in want and kk.split("<")[0] == want) or ("<" in want and kk.startswith(want[:-1] + ",")):
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
     return round(b / n) if n else None
@@ -322,7 +323,10 @@ def main():
             dom = max(rows, key=lambda r: r["ms"])
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            peak_tf = PEAK_TFLOPS[args.precision]
+            # fp8 mode: only the e4m3 Linear instantiations (last template argument `true`) are priced against the fp8 peak;
+            # attention, weight gradients and LayerNorm run their MFMAs in bf16 in that mode too
+            fp8_kernel = args.precision == "fp8" and (dom["name"].startswith(("tlin_", "wst_")) and dom["name"].rstrip(">").endswith("true"))
+            peak_tf = PEAK_TFLOPS["fp8"] if fp8_kernel else PEAK_TFLOPS["f32" if args.precision == "f32" else "bf16"]
             frac_m, frac_h = tf / peak_tf, gbs / PEAK_HBM_GBS
             # which roof: the kernel's arithmetic intensity against the machine's ridge point (FLOP per HBM byte)
             intensity = dom["flops"] / max(dom["bytes"], 1.0)
