@@ -1266,16 +1266,14 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         }
     }
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
-    const float* dx0 = dx;
     const float* dtok = e->s_dtokrep;
     if (Rb > 1) {
-        KL(k_fold(e->s_dx0, dx, (long)B * S * E, Rb, c.st));
         if (e->xattn && !i2t_sh) KL(k_fold(e->s_dtok, e->s_dtokrep, (long)B * T * E, Rb, c.st));
-        dx0 = e->s_dx0;
         if (!i2t_sh) dtok = e->s_dtok;
     }
-    KL(k_cls_grad(dx0, g + n.cls, B, S, E, c.st));
-    KL(k_gather_patch_rows(e->s_demb, dx0, B, P, E, c.st));
+    // one pass over dx: replicas summed, patch rows -> s_demb, CLS rows -> the head of s_dx0 (scratch from here on)
+    KL(k_fold_gather(e->s_demb, e->s_dx0, dx, B, S, E, Rb, c.st));
+    KL(k_cls_grad(e->s_dx0, g + n.cls, B, 1, E, c.st));
     if (e->pe_ln) {
         // Linear -> ReLU -> LayerNorm patch encoder, no FiLM: LayerNorm backward on the saved ReLU output, ReLU mask from the
         // same tensor (h > 0), then the plain weight / bias gradients against the raw patches

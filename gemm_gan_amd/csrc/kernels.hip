@@ -515,7 +515,12 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
 
 int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out,
                     float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st, int dres_bf16) {
-    const unsigned nb = nblocks(rows, 4 * 16, 4096);   // >=16 rows per wave so the atomics are amortised
+    // Rows per wave: the kernel ends with 3 x E atomic adds per workgroup into the SAME E addresses (gamma / beta / bias
+    // gradients), which serialise per address at the memory side - at 16 rows per wave (2 056 workgroups for the 131 584
+    // rows of a backward pass) that tail was a fifth of the kernel (122 us); 32 rows: 99 us (4.4 TB/s), 64 rows: too few
+    // waves per CU to cover the load latency (125 us).  GG_LN_ROWS overrides for measurements.
+    static const int ln_rows = getenv("GG_LN_ROWS") ? atoi(getenv("GG_LN_ROWS")) : 32;
+    const unsigned nb = nblocks(rows, 4 * ln_rows, 4096);
     const bool al = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) |
                       reinterpret_cast<uintptr_t>(dr) | reinterpret_cast<uintptr_t>(dres_out)) & 15) == 0;
     if (E % 4 == 0 && E <= 1024 && al) {
@@ -1058,6 +1063,33 @@ __global__ void scatter_patch_rows_k(float* seq, const float* in, int B, int P, 
 }
 int k_scatter_patch_rows(float* seq, const float* in, int B, int P, int E, hipStream_t st) {
     scatter_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(seq, in, B, P, E);
+    GG_LAUNCH_CHECK();
+}
+// Fold the R replicas of the layer-0 input gradient dx [R][B][S][E] and split it in the same pass: patch rows (s >= 1) go
+// to demb [B*(S-1)][E], the CLS rows (s == 0) to cls_rows [B][E].  One read of dx, float4 accesses - replaces fold_k (scalar
+// loads, a full [B,S,E] intermediate) + gather_patch_rows_k (a second read and write of the same 67 MB).
+__global__ __launch_bounds__(TPB) void fold_gather_k(float* __restrict__ demb, float* __restrict__ cls_rows, const float* __restrict__ dx,
+                                                     int B, int S, int E, int R) {
+    const long n4 = (long)B * S * E / 4, rep = (long)B * S * E;
+    const int E4 = E / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / E4;                       // b * S + s
+        const int c = (int)(i - row * E4) * 4;
+        const long b = row / S;
+        const int sidx = (int)(row - b * S);
+        const float* src = dx + row * E + c;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        if (R > 1) v += *reinterpret_cast<const f32x4*>(src + rep);
+        if (R > 2) v += *reinterpret_cast<const f32x4*>(src + 2 * rep);
+        for (int r = 3; r < R; ++r) v += *reinterpret_cast<const f32x4*>(src + r * rep);
+        float* dst = sidx == 0 ? cls_rows + b * E + c : demb + (row - b - 1) * E + c;
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
+}
+int k_fold_gather(float* demb, float* cls_rows, const float* dx, int B, int S, int E, int R, hipStream_t st) {
+    GG_REQUIRE(E % 4 == 0 && ((reinterpret_cast<uintptr_t>(demb) | reinterpret_cast<uintptr_t>(cls_rows) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+               "fold_gather: 16-byte aligned rows expected");
+    fold_gather_k<<<nblocks((long)B * S * E / 4, TPB, 16384), TPB, 0, st>>>(demb, cls_rows, dx, B, S, E, R);
     GG_LAUNCH_CHECK();
 }
 int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st) {

@@ -43,7 +43,9 @@ def test_graph_route_equals_eager_route(case, precision, optimizer):
     cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
     torch.manual_seed(11)
     tr = Trainer(cfg)
-    n, steps = 3, 6
+    # n_critic = 1: the critic losses of a step are then computed from the weights both engines were GIVEN (tight gate);
+    # the generator loss follows one critic update and is compared loosely in bf16, the parameters by count
+    n, steps = 1, 6
     (x, patches, patch_pad, text, text_pad), zs, als = _inputs(cfg, B, P, T, n)
     eager = engine_from_cfg(cfg, B, P, T, dropout=0.0, optimizer=optimizer)
     graph = engine_from_cfg(cfg, B, P, T, dropout=0.0, optimizer=optimizer)
@@ -61,7 +63,8 @@ def test_graph_route_equals_eager_route(case, precision, optimizer):
         init = {r: eager.flat[r]["w"].clone() for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC)}
         for e in (eager, graph):
             e.train_step(x, patches, patch_pad, text, text_pad, zs[s], als[s])
-        ck.check(f"step {s}: losses", graph.losses[:4], eager.losses[:4])
+        ck.check(f"step {s}: critic losses", graph.losses[:3], eager.losses[:3])
+        ck.check(f"step {s}: generator loss", graph.losses[3:4], eager.losses[3:4], 1e-3 if f32 else 0.3)
         for r, name, k in ((L.ROLE_CRITIC, "critic", n), (L.ROLE_GENERATOR, "generator", 1)):
             ck.check_post(f"step {s}: {name} parameters", graph.flat[r]["w"], eager.flat[r]["w"].cpu().numpy(), init[r].cpu().numpy(),
                           optimizer, lr[r], k if optimizer == "rms_prop" else s * k + k, rtol=1e-3 if f32 else 5e-2, share=0.03 if f32 else 0.15)
