@@ -1126,21 +1126,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
     const uint32_t stile = drop_state(drop, (((uint64_t)nhid * S) * Sd) / 2 + (uint64_t)(key >> 1)) + (uint32_t)(par + 4 * h) * rowmul;
     const int shl = par ? 0 : 16;                      // odd element -> high half, even element -> low half
     const uint32_t thr_hi = drop.thr << 16;
+    // The query tile of the NEXT iteration is requested while this one is multiplied (register double buffer): every one
+    // of the nqt iterations used to begin with a global round trip that the two resident waves per SIMD do not cover.
+    bf16x8 qn[KS], dn[KS];
+    float lsn = 0.f, dln = 0.f;
+    auto request = [&](int qt) {
+        const int qc = min(qt * 32 + c, S - 1);        // rows past the end: finite duplicates, zeroed by (qq < S) below
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qn[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+            dn[s] = load_frag8<IOB>(dctx, dbase + (long)qc * E + 16 * s + 8 * h);
+        }
+        lsn = lse2[nhid * S + qc];
+        dln = delta[nhid * S + qc];
+    };
+    request(0);
     for (int qt = 0; qt < nqt; ++qt) {
         const int q = qt * 32 + c;
         bf16x8 qa[KS], da[KS];
-        const int qc = min(q, S - 1);                  // rows past the end: finite duplicates, zeroed by (qq < S) below
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qa[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
-            da[s] = load_frag8<IOB>(dctx, dbase + (long)qc * E + 16 * s + 8 * h);
+            qa[s] = qn[s];
+            da[s] = dn[s];
             *reinterpret_cast<bf16x8*>(qimg + c * LDR + 16 * s + 8 * h) = qa[s];
             *reinterpret_cast<bf16x8*>(dimg + c * LDR + 16 * s + 8 * h) = da[s];
         }
         if (h == 0) {
-            Ls[wave][c] = q < S ? lse2[nhid * S + q] : 0.f;
-            Dl[wave][c] = q < S ? delta[nhid * S + q] : 0.f;
+            Ls[wave][c] = q < S ? lsn : 0.f;
+            Dl[wave][c] = q < S ? dln : 0.f;
         }
+        if (qt + 1 < nqt) request(qt + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

@@ -32,7 +32,9 @@ __device__ __forceinline__ uint32_t drop_fmix32(uint32_t h) {
 // at kernel entry (a scalar load + 5 scalar ALU ops).  Forward and backward kernels of a step read the same word.
 __device__ __forceinline__ DropKey drop_live(DropKey k) {
     if (k.epoch) {
-        uint32_t h = k.k0 + __builtin_nontemporal_load(k.epoch) * 0x632BE5ABu;
+        // readfirstlane: the word is the same for every lane, and everything derived from k0 (row states, hash inputs) must
+        // stay in scalar registers - a vector-loaded k0 doubled the VGPR count of the attention kernels
+        uint32_t h = k.k0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)*k.epoch) * 0x632BE5ABu;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
         k.k0 = h;
     }
