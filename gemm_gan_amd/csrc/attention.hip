@@ -94,34 +94,60 @@ __device__ __forceinline__ void store4(void* base, long off, f32x4 v) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- LDS staging -------------------------------------------------------------------------------------
-// row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled
+// row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled.
+// Loads are unconditional from clamped rows, four per thread in flight, zero-fill by select at the LDS write: a guard
+// around the load made every iteration of the loop one serialised memory round trip (9 of them for S = 257).
 template <int DH, bool IOB>
 __device__ __forceinline__ void stage_rows(__bf16* img, const void* X, long xoff, long ldx, int S, int Sp, int tid, int nthreads) {
-    constexpr int LD = DH + 8;
+    constexpr int LD = DH + 8, U = 4;
     const int nchunk = Sp * (DH / 8);
-    for (int c = tid; c < nchunk; c += nthreads) {
-        const int row = c / (DH / 8), c8 = c % (DH / 8);
-        bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < S) w = load_frag8<IOB>(X, xoff + (long)row * ldx + 8 * c8);
-        *reinterpret_cast<bf16x8*>(img + row * LD + 8 * c8) = w;
+    if (S <= 0) {                                       // nothing valid to read (never the case for the callers' chunking)
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = tid; c < nchunk; c += nthreads) *reinterpret_cast<bf16x8*>(img + (c / (DH / 8)) * LD + 8 * (c % (DH / 8))) = z;
+        return;
+    }
+    const int rmax = S - 1;
+    for (int c0 = tid; c0 < nchunk; c0 += U * nthreads) {
+        bf16x8 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = min(c0 + u * nthreads, nchunk - 1);
+            const int row = c / (DH / 8), c8 = c % (DH / 8);
+            w[u] = load_frag8<IOB>(X, xoff + (long)min(row, rmax) * ldx + 8 * c8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            if (c < nchunk) {
+                const int row = c / (DH / 8), c8 = c % (DH / 8);
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<bf16x8*>(img + row * LD + 8 * c8) = row < S ? w[u] : z;
+            }
+        }
     }
 }
-// transposed image  img[d][row] (ld = Sp+8 bf16) of X[row, col0 + d]
+// transposed image  img[d][row] (ld = Sp+8 bf16) of X[row, col0 + d]  (same loading discipline)
 template <int DH, bool IOB>
 __device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, long xoff, long ldx, int S, int Sp, int tid, int nthreads) {
     const int LD = Sp + 8;
     const int nunit = (Sp / 8) * (DH / 4);
+    if (S <= 0) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int u = tid; u < nunit; u += nthreads)
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8*>(img + (4 * (u % (DH / 4)) + q) * LD + 8 * (u / (DH / 4))) = z;
+        return;
+    }
+    const int rmax = S - 1;
     for (int u = tid; u < nunit; u += nthreads) {
         const int r8 = u / (DH / 4), d4 = u % (DH / 4);
         if constexpr (IOB) {
             const __bf16* Xb = reinterpret_cast<const __bf16*>(X) + xoff;
             s16x4_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = 8 * r8 + j;
-                v[j] = s16x4_t{0, 0, 0, 0};
-                if (row < S) v[j] = *reinterpret_cast<const s16x4_t*>(Xb + (long)row * ldx + 4 * d4);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const s16x4_t*>(Xb + (long)min(8 * r8 + j, rmax) * ldx + 4 * d4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * r8 + j >= S) v[j] = s16x4_t{0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bf16x8 w;
@@ -133,11 +159,10 @@ __device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, lon
             const float* Xf = reinterpret_cast<const float*>(X) + xoff;
             f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = 8 * r8 + j;
-                v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < S) v[j] = *reinterpret_cast<const f32x4*>(Xf + (long)row * ldx + 4 * d4);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(Xf + (long)min(8 * r8 + j, rmax) * ldx + 4 * d4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * r8 + j >= S) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 w = {pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q]), pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};

@@ -194,16 +194,19 @@ def test_training_trajectories_bf16_vs_f32_at_the_headline_shape():
     assert np.isfinite(a).all() and np.isfinite(b).all()
     # GAN training amplifies any perturbation (each train() takes six sign-like RMSprop steps) and the first ~10 steps of
     # BOTH runs show isolated loss spikes, at different steps: the runs are compared as trajectories once they have settled
-    # (steps >= 12): critic loss within 30 % step by step (both runs oscillate with period 2 around their trend, the f32 one
-    # by +-8 %, and the phases need not agree) and within 8 % on the mean of the last ten steps, 15 % for the
+    # (isolated spikes occur up to step ~14 in either run, the f32 one included): critic loss within 15 % on two-step averages
+    # from step 16 on and within 8 % on the mean of the last ten steps, 15 % for the
     # gradient penalty level; the generator loss (-mean D(G(z)), a difference of large numbers) is recorded.
     late = slice(12, None)
-    dev_d = float((np.abs(a[late, 0] - b[late, 0]) / np.abs(b[late, 0])).max())
+    # both runs oscillate with period 2 around their trend (by +-8 .. 15 %, with phases that need not agree): the step-by-step
+    # comparison is made on the averages of consecutive step pairs
+    pa, pb = (a[16:-1, 0] + a[17:, 0]) / 2, (b[16:-1, 0] + b[17:, 0]) / 2
+    dev_d = float((np.abs(pa - pb) / np.abs(pb)).max())
     md_a, md_b = a[-10:, 0].mean(), b[-10:, 0].mean()
     gp_a, gp_b = a[-10:, 2].mean(), b[-10:, 2].mean()
-    diag(f"   critic loss: max deviation {dev_d:.3f} over steps >= 12, mean of the last ten bf16 {md_a:.2f} f32 {md_b:.2f}; "
+    diag(f"   critic loss: max deviation {dev_d:.3f} on two-step averages from step 16, mean of the last ten bf16 {md_a:.2f} f32 {md_b:.2f}; "
          f"gp level bf16 {gp_a:.3f} f32 {gp_b:.3f}; generator loss, last ten: bf16 {a[-10:, 1].mean():.2f} f32 {b[-10:, 1].mean():.2f}")
     # (run-to-run, fp32 atomics alone move these by a few percent: the runs are chaotic systems started from the same point)
-    assert dev_d <= 0.30, dev_d
+    assert dev_d <= 0.15, dev_d
     assert abs(md_a - md_b) <= 0.08 * abs(md_b), (md_a, md_b)
     assert abs(gp_a - gp_b) <= 0.15 * gp_b, (gp_a, gp_b)
