@@ -446,8 +446,29 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
         const int c = 4 * lane + 256 * j;
         gw[j] = c < E ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long row = blockIdx.x * 4L + wave; row < rows; row += gridDim.x * 4L) {
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    // The next row's loads are issued before this row is reduced (register double buffer; rows past the end re-read the
+    // last row and are not used): a load - reduce - store loop exposes one memory round trip per row to each wave.
+    const long rstep = gridDim.x * 4L;
+    long row = blockIdx.x * 4L + wave;
+    f32x4 nd[NV], nr[NV];
+    float nmean = 0.f, nrstd = 0.f;
+    auto request = [&](long rw) {
+        const long rc = min(rw, rows - 1);
+        nmean = stats[2 * rc]; nrstd = stats[2 * rc + 1];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = min(4 * lane + 256 * j, E - 4);
+            nd[j] = *reinterpret_cast<const f32x4*>(dy + rc * E + c);
+            nr[j] = *reinterpret_cast<const f32x4*>(r + rc * E + c);
+        }
+    };
+    if (row < rows) request(row);
+    for (; row < rows; row += rstep) {
+        const float mean = nmean, rstd = nrstd;
+        f32x4 cd[NV], cr[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { cd[j] = nd[j]; cr[j] = nr[j]; }
+        request(row + rstep);
         f32x4 xh[NV], dxh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -455,8 +476,8 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
             const int c = 4 * lane + 256 * j;
             xh[j] = dxh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < E) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * E + c);
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(r + row * E + c);
+                const f32x4 d = cd[j];
+                const f32x4 rv = cr[j];
                 xh[j] = (rv - mean) * rstd;
                 dxh[j] = d * gw[j];
                 pg[j] += d * xh[j];
