@@ -265,6 +265,8 @@ def main():
     if prof:
         rows = w.engine.profile_collect()
         w.engine.profile(False)
+    launches_per_step = w.engine.launch_count()        # of the last timed step (the parity-mode leg below has its own count)
+    graph_stats = w.engine.graph_stats() if w.engine.graph else None
     comm_ms = w.comm_wait_ms() / args.steps if world > 1 else 0.0
     t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
     if world > 1:
@@ -311,8 +313,8 @@ def main():
                                       + f"per-GPU batch {B}, {G} genes, {P} patch tokens x1024, {T} text token x{args.text_dims}, "
                                       f"n_critic=5, rms_prop, dropout {args.dropout}"
                                       + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
-                          "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": w.engine.launch_count(),
-                          "hip_graph": w.engine.graph_stats() if w.engine.graph else None,
+                          "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": launches_per_step,
+                          "hip_graph": graph_stats,
                           "allreduce_wait_ms_per_step": round(comm_ms, 3) if world > 1 else None},
                "finite": finite,
                "losses": {"d": losses_head[0], "g": losses_head[1]}}
