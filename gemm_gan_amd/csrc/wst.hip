@@ -46,9 +46,15 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // F8: e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (see tlin.hip "fp8 operand path"): W from the e4m3 shadow (half the
 // weight registers: N = 768 fits), X quantised to e4m3 while staging, a lane's fragment = 32 consecutive k (32 bytes).
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false>
+// GROUPS > 1: the output has GROUPS * N columns (the packed QKV projection: 3 x 256) and the grid holds GROUPS workgroups per
+// token-tile owner, each stationary on its own N rows of W and streaming the SAME tiles; the block index is decoded so that
+// the groups of one owner sit on one XCD (ids that differ by multiples of 8) and re-read the tile from that XCD's L2.
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
 __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
+    const int grp = GROUPS > 1 ? (int)(blockIdx.x >> 3) % GROUPS : 0;
+    const long owner = GROUPS > 1 ? (long)(blockIdx.x / (8 * GROUPS)) * 8 + (blockIdx.x & 7) : (long)blockIdx.x;
+    const long nown = GROUPS > 1 ? (long)gridDim.x / GROUPS : (long)gridDim.x;
     constexpr int K = 16 * KS, N = 32 * NW * RT, NTH = 64 * NW;
     constexpr int ESZ = F8 ? 1 : 2;                     // bytes per operand element in LDS
     constexpr int XLD = F8 ? K + 16 : K + 8;            // elements per LDS row: 4 banks per row step, conflict-free 16-byte reads
@@ -64,7 +70,8 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
-    const int f0 = 32 * RT * wave;                      // first output feature of this wave
+    const int f0 = 32 * RT * wave;                      // first output feature of this wave (inside its column group)
+    const int gcol = grp * (32 * NW * RT);              // first output column of this workgroup's group
     const long ntiles = (p.M + TT - 1) / TT;
     const int last_tok = (int)p.M - 1;
 
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
         const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const __bf16* wr = Wp + (long)(f0 + 32 * rt + a_row_of_lane(c)) * p.ldw + 8 * h;
+            const __bf16* wr = Wp + (long)(gcol + f0 + 32 * rt + a_row_of_lane(c)) * p.ldw + 8 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s) wA[rt][s] = *reinterpret_cast<const bf16x8*>(wr + 16 * s);
         }
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     const int sc_w = F8 ? 127 - *p.w_exp : 0, sc_x = F8 ? 127 - p.x_exp : 0;
     const float xscale = F8 ? exp2i(p.x_exp) : 1.f;
     for (int i = tid; i < N; i += NTH) {
-        Ps[i] = p.bias ? p.bias[i] : 0.f;
+        Ps[i] = p.bias ? p.bias[gcol + i] : 0.f;
         if constexpr (EPI == EPI_LN) {
             Ps[N + i] = p.ln_g[i];
             Ps[2 * N + i] = p.ln_b[i];
@@ -137,16 +144,16 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
         }
     };
 
-    long tile = blockIdx.x;
+    long tile = owner;
     if (tile >= ntiles) return;
     load_x(tile);
     store_x(0);
-    if (tile + gridDim.x < ntiles) load_x(tile + gridDim.x);
+    if (tile + nown < ntiles) load_x(tile + nown);
     const float ksd = p.drop.p > 0.f ? 1.f / (1.f - p.drop.p) : 1.f;
     const bool drop_on = p.drop.p > 0.f;
 
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < ntiles; tile += nown, buf ^= 1) {
         const int tok = (int)(tile * TT) + c;
         const bool valid = tok <= last_tok;
         const int tokc = valid ? tok : last_tok;        // clamped lanes recompute the last row; their stores are predicated off
@@ -201,13 +208,13 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
             }
         }
         // the next tile's rows (already in registers) go to the other buffer, the tile after that is requested
-        if (tile + gridDim.x < ntiles) {
+        if (tile + nown < ntiles) {
             store_x(buf ^ 1);
-            if (tile + 2L * gridDim.x < ntiles) load_x(tile + 2L * gridDim.x);
+            if (tile + 2L * nown < ntiles) load_x(tile + 2L * nown);
         }
         if constexpr (EPI != EPI_LN) {
             // ---- plain epilogues: no cross-wave step, one barrier per tile ------------------------------------------
-            const uint64_t dbase2 = (uint64_t)tokc * p.drop_ld + f0 + 16 * h;
+            const uint64_t dbase2 = (uint64_t)tokc * p.drop_ld + gcol + f0 + 16 * h;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 unsigned packed[8];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
                 }
                 if constexpr (EPI == EPI_ACT || EPI == EPI_MASK) {
                     if (valid) {
-                        __bf16* yo = reinterpret_cast<__bf16*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h + 32 * rt;
+                        __bf16* yo = reinterpret_cast<__bf16*>(p.Y) + (long)tokc * p.ldy + gcol + f0 + 16 * h + 32 * rt;
                         *reinterpret_cast<u32x4*>(yo) = u32x4{packed[0], packed[1], packed[2], packed[3]};
                         *reinterpret_cast<u32x4*>(yo + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
                     }
@@ -316,14 +323,15 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
     }
 }
 
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false>
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
 int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    static_assert(GROUPS == 1 || (EPI == EPI_ACT && !F8), "column groups: plain bf16-output epilogue only");
     constexpr int K = 16 * KS, N = 32 * NW * RT;
     constexpr size_t smem = (size_t)2 * TT * (F8 ? K + 16 : (K + 8) * 2) + (size_t)2 * NW * TT * 2 * 4 + (size_t)3 * N * 4;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int dev = 0;
         GG_CHECK_HIP(hipGetDevice(&dev));
         GG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -331,9 +339,13 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     }
     const long ntiles = (p.M + TT - 1) / TT;
     const long slots = (long)n_cu * (NW == 4 ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8
-    const unsigned grid = (unsigned)std::min<long>(ntiles, slots);
-    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
-    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8>), dim3(grid), dim3(64 * NW), smem, st, p);
+    unsigned grid = (unsigned)std::min<long>(ntiles, slots);
+    if (GROUPS > 1) {       // owners in whole groups of 8 (one per XCD), GROUPS workgroups each
+        const long owners = std::max<long>(8, std::min<long>((ntiles + 7) / 8 * 8, slots / GROUPS / 8 * 8));
+        grid = (unsigned)(owners * GROUPS);
+    }
+    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
+    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), dim3(grid), dim3(64 * NW), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -362,6 +374,7 @@ int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
 //   3  y (bf16) = (X W^T) gated by ref, N = 512, K = 256, bf16 X          (dh = dres W2 * [h > 0])
 //   4  y (bf16) = act(X W^T + b), N = 256, K = 256, bf16 X              (dctx = dres Wo)
 //   5  as 1 with K = 768                                                 (dx += dqkv Win)
+//   6  y (bf16) = X W^T + b, N = 768 = 3 column groups of 256, K = 256, fp32 X   (packed QKV projection, forward)
 int wst_kind(const TlinP& p) {
     if (p.fp8 || p.ln_g || p.res || p.film_g || p.y_row_group || p.M < 1) return 0;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 8 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
@@ -374,6 +387,10 @@ int wst_kind(const TlinP& p) {
         return p.K == 512 ? 1 : 5;
     if (!p.accumulate && !p.mask_ref && p.y_bf16 && p.x_bf16 && p.N == 256 && p.K == 256 && p.ldy % 8 == 0) return 4;
     if (!p.accumulate && !p.mask_ref && p.y_bf16 && !p.x_bf16 && p.N == 512 && p.K == 256 && p.ldy % 8 == 0) return 2;
+    static const bool no_qkv = getenv("GG_NO_WST_QKV") != nullptr;
+    if (!no_qkv && !p.accumulate && !p.mask_ref && p.y_bf16 && !p.x_bf16 && p.N == 768 && p.K == 256 && p.ldy % 8 == 0 && !p.act_relu &&
+        p.drop.p == 0.f)
+        return 6;
     if (!p.accumulate && p.mask_ref && p.mask_bf16 && p.y_bf16 && p.x_bf16 && p.N == 512 && p.K == 256 && !p.act_relu &&
         p.drop.p == 0.f && !p.bias && p.ldy % 8 == 0 && p.ldref % 8 == 0 && al16(p.mask_ref))
         return 3;
@@ -410,6 +427,7 @@ int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         case 3: return launch<8, 2, 16, true, EPI_MASK>(p, st, ev0, ev1);
         case 4: return launch<4, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
         case 5: return launch<8, 1, 48, true, EPI_ACC>(p, st, ev0, ev1);
+        case 6: return launch<4, 2, 16, false, EPI_ACT, false, 3>(p, st, ev0, ev1);
     }
     set_error("wst_other: no instantiation for this call");
     return -2;
