@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     Stager<XB, PK> sx[DEPTH];
     const long nch = c_end - c_beg;
 #ifndef GG_WG_ABL
-#define GG_WG_ABL 0          // tools/wgrad_probe.hip ablations: 1 = no fragment reads / MFMAs, 2 = no LDS writes of X
+#define GG_WG_ABL 0          // tools/wgrad_probe.hip ablations: 1 = no fragment reads / MFMAs, 2 = no LDS writes of X, 4 = no atomic
+                             // panel add (measured: the add costs 15 - 21 us of a 55 - 125 us launch; it scales with
+                             // splits x N x K, and smaller panels / fewer splits pay more in L2 re-reads than they save)
 #endif
     auto multiply = [&](int buf) {
 #pragma unroll
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int rr = a * 32 + (i & 3) + 8 * (i >> 2);       // row inside the wave's slice (minus 4h)
-                    if (nb + 4 * h + rr < nvalid) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
+                    if (nb + 4 * h + rr < nvalid && !((GG_WG_ABL & 4) && acc[a][b][i] != 12345.f)) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one tile's accumulators at a time: no mass copy-out (spills)
