@@ -94,6 +94,12 @@ __device__ __forceinline__ void store4(void* base, long off, f32x4 v) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- LDS staging -------------------------------------------------------------------------------------
+// Row padding of the TRANSPOSED images img[d][row] (Vt of the forward, Kt of the dQ kernels).  A lane reads 8 bytes of row
+// d = its index c: with a row stride of (rows + 8) bf16 = 4 * odd dwords, lanes c and c + 16 of a 32-lane group hit the same
+// banks (half of the LDS cycles of these kernels were conflict cycles, SQ_LDS_BANK_CONFLICT); (rows + 12) bf16 = 2 * odd
+// dwords spreads 32 lanes over all 64 banks.  The rows are then only 8-byte aligned: the staging writes go out as two
+// 8-byte stores.
+constexpr int TPAD = 12;
 // row-major image  img[row][d] (ld = DH+8 bf16) of X[row, col0 + d], rows >= S zero-filled.
 // Loads are unconditional from clamped rows, four per thread in flight, zero-fill by select at the LDS write: a guard
 // around the load made every iteration of the loop one serialised memory round trip (9 of them for S = 257).
@@ -129,12 +135,13 @@ __device__ __forceinline__ void stage_rows(__bf16* img, const void* X, long xoff
 // transposed image  img[d][row] (ld = Sp+8 bf16) of X[row, col0 + d]  (same loading discipline)
 template <int DH, bool IOB>
 __device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, long xoff, long ldx, int S, int Sp, int tid, int nthreads) {
-    const int LD = Sp + 8;
+    const int LD = Sp + TPAD;
     const int nunit = (Sp / 8) * (DH / 4);
     if (S <= 0) {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int u = tid; u < nunit; u += nthreads)
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8*>(img + (4 * (u % (DH / 4)) + q) * LD + 8 * (u / (DH / 4))) = z;
+            for (int q = 0; q < 4; ++q)
+                for (int hh = 0; hh < 2; ++hh)
+                    *reinterpret_cast<s16x4_t*>(img + (4 * (u % (DH / 4)) + q) * LD + 8 * (u / (DH / 4)) + 4 * hh) = s16x4_t{0, 0, 0, 0};
         return;
     }
     const int rmax = S - 1;
@@ -150,10 +157,11 @@ __device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, lon
                 if (8 * r8 + j >= S) v[j] = s16x4_t{0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bf16x8 w;
+                s16x4_t w0, w1;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = v[j][q];
-                *reinterpret_cast<bf16x8*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+                for (int j = 0; j < 4; ++j) { w0[j] = v[j][q]; w1[j] = v[4 + j][q]; }
+                *reinterpret_cast<s16x4_t*>(img + (4 * d4 + q) * LD + 8 * r8) = w0;
+                *reinterpret_cast<s16x4_t*>(img + (4 * d4 + q) * LD + 8 * r8 + 4) = w1;
             }
         } else {
             const float* Xf = reinterpret_cast<const float*>(X) + xoff;
@@ -165,8 +173,8 @@ __device__ __forceinline__ void stage_transposed(__bf16* img, const void* X, lon
                 if (8 * r8 + j >= S) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                u32x4 w = {pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q]), pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};
-                *reinterpret_cast<u32x4*>(img + (4 * d4 + q) * LD + 8 * r8) = w;
+                *reinterpret_cast<u32x2*>(img + (4 * d4 + q) * LD + 8 * r8) = u32x2{pack2(v[0][q], v[1][q]), pack2(v[2][q], v[3][q])};
+                *reinterpret_cast<u32x2*>(img + (4 * d4 + q) * LD + 8 * r8 + 4) = u32x2{pack2(v[4][q], v[5][q]), pack2(v[6][q], v[7][q])};
             }
         }
     }
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
-    const int LDV = Sp + 8;
+    const int LDV = Sp + TPAD;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vt = Ks + Sp * LDK;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vt + DH * LDV);
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
-    const int LDV = CK + 8;                     // one chunk of CK keys (multiple of 32) is resident at a time
+    const int LDV = CK + TPAD;                     // one chunk of CK keys (multiple of 32) is resident at a time
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vt = Ks + CK * LDK;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vt + DH * LDV);
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const void* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Sp = (S + 31) / 32 * 32;
     constexpr int LDK = DH + 8;
-    const int LDT = Sp + 8;
+    const int LDT = Sp + TPAD;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vs = Ks + Sp * LDK;
     __bf16* Kt = Vs + Sp * LDK;
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const void* __rest
     const int ckt = (nkt + 1) / 2;                  // key tiles per chunk
     const int CK = ckt * 32;                        // keys per chunk
     constexpr int LDK = DH + 8;
-    const int LDT = CK + 8;
+    const int LDT = CK + TPAD;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vs = Ks + CK * LDK;
     __bf16* Kt = Vs + CK * LDK;
@@ -924,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const void* __
     const int ckt = CK / 32;                        // key tiles per chunk (CK keys, a multiple of 32, resident at a time)
     const int nch = (nkt + ckt - 1) / ckt;
     constexpr int LDK = DH + 8;
-    const int LDT = CK + 8;
+    const int LDT = CK + TPAD;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vs = Ks + CK * LDK;
     __bf16* Kt = Vs + CK * LDK;
@@ -1263,27 +1271,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
 
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
+    return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 size_t dq_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
+    return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 
 size_t dq2_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
     const int CK = ((Sp / 32 + 1) / 2) * 32;
-    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
+    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
 }
 // long-sequence kernels: keys stream through LDS in chunks of CK (a multiple of 32) chosen so that two workgroups share a CU
 constexpr int LONG_MAX_S = 2048;                 // 64 key-tile flags
 size_t fwd_long_smem(int S, int DH, int CK) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16;
+    return (size_t)CK * (DH + 8) * 2 + (size_t)DH * (CK + TPAD) * 2 + Sp + 64 + 16;
 }
 size_t dq_long_smem(int S, int DH, int CK) {
     const int Sp = (S + 31) / 32 * 32;
-    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + 8) * 2 + Sp + 64 + 16;
+    return (size_t)2 * CK * (DH + 8) * 2 + (size_t)DH * (CK + TPAD) * 2 + Sp + 64 + 16;
 }
 template <typename F>
 int long_chunk(int S, int DH, F smem) {         // largest chunk with 2 * smem <= 160 KB (at least one key tile)
