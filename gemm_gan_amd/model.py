@@ -315,6 +315,8 @@ class WGAN_GP:
         """Asynchronous SUM all-reduce of one of the two gradient buckets: 'mlp' = the MLP-head slots (complete after the
         head phase of the backward), 'cond' = the conditioning-stack slots (complete at its end)."""
         import torch.distributed as dist
+        if self._world() == 1:          # GG_FORCE_DP_LOOP=1 at world size 1: the host loop without its collectives (measurement)
+            return None
         off, numel = self.engine.mlp_range[role]
         g = self.engine.flat[role]["g"]
         t = g[off:off + numel] if which == "mlp" else g[:off]
@@ -496,7 +498,7 @@ class WGAN_GP:
         self._sync_lr()
         w = self._world()
         n = alpha_all.shape[0]
-        if w == 1:
+        if w == 1 and os.environ.get("GG_FORCE_DP_LOOP") != "1":
             eng.train_step(x, pat, ppad, text, tpad, z_all, alpha_all)     # whole step enqueued by ONE C call
         else:
             # One flat-buffer SUM all-reduce per optimiser step, issued as two buckets so that it overlaps the backward
