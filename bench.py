@@ -372,6 +372,14 @@ def main():
                                                 "under their own classes below); every tensor of the chain is <= B*G*4 = "
                                                 f"{B * G * 4 / 1e6:.1f} MB, i.e. <= {B * G * 4 / 8e6:.2f} us at the HBM peak: launch-latency-"
                                                 "bound by construction at this minibatch",
+                               "time_weighted": (lambda rs: {
+                                   "note": "all classes of the table, each priced against the roof its algorithmic intensity falls under "
+                                           "(HBM below the ridge, MFMA above), weighted by their time in the serialised step",
+                                   "frac": round(sum(r["ms"] * (r["bytes"] / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+                                                                if r["flops"] / max(r["bytes"], 1.0) < ridge else
+                                                                r["flops"] / (r["ms"] * 1e-3) / 1e12 / peak_tf) for r in rs) /
+                                                 max(sum(r["ms"] for r in rs), 1e-9), 4),
+                                   "ms": round(sum(r["ms"] for r in rs), 2)})([r for r in (rows_all or rows) if r["ms"] > 0]),
                                "kernel_classes_note": ("one untimed warm-up step with event pairs on every class, streams serialised; "
                                                        "algorithmic FLOPs and bytes per class (tensors once at their stored "
                                                        "element sizes)") if rows_all else "timed region",
