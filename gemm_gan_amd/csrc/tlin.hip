@@ -98,30 +98,44 @@ __device__ __forceinline__ void stage_x(const TlinP& p, __bf16* xs, int tok0, in
             const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b) + cb;
             const f32x4 ga = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g0 * fldb), ba = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g0 * fldb);
             const f32x4 gb = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g1 * fldb), bb = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g1 * fldb);
+            // two batches of GB loads alternate: batch b + 1 is requested before batch b is modulated and written to LDS, so
+            // a slice costs one exposed round trip instead of NLD / GB of them (the kernel runs one wave per SIMD)
+            f32x4 v[2][GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) v[0][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
 #pragma unroll
             for (int b0 = 0; b0 < NLD; b0 += GB) {
-                f32x4 v[GB];
+                const int cur = (b0 / GB) & 1;
+                if (b0 + GB < NLD) {
 #pragma unroll
-                for (int i = 0; i < GB; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + i), last_tok) * ldb + cb));
+                    for (int i = 0; i < GB; ++i)
+                        v[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + GB + i), last_tok) * ldb + cb));
+                }
 #pragma unroll
                 for (int i = 0; i < GB; ++i) {
                     const int r = min(tok0 + lrow + RPI * (b0 + i), last_tok);
                     const bool second = rem0 + (r - tb) >= p.film_group;
-                    const f32x4 m = (second ? gb : ga) * v[i] + (second ? bb : ba);
+                    const f32x4 m = (second ? gb : ga) * v[cur][i] + (second ? bb : ba);
                     u32x2 w = {pack2(m[0], m[1]), pack2(m[2], m[3])};
                     *reinterpret_cast<u32x2*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = w;
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads out of this one's registers
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            f32x4 v[2][GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) v[0][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
 #pragma unroll
             for (int b0 = 0; b0 < NLD; b0 += GB) {
-                f32x4 v[GB];
+                const int cur = (b0 / GB) & 1;
+                if (b0 + GB < NLD) {
 #pragma unroll
-                for (int i = 0; i < GB; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + i), last_tok) * ldb + cb));
+                    for (int i = 0; i < GB; ++i)
+                        v[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + GB + i), last_tok) * ldb + cb));
+                }
 #pragma unroll
                 for (int i = 0; i < GB; ++i) {
-                    u32x2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
+                    u32x2 w = {pack2(v[cur][i][0], v[cur][i][1]), pack2(v[cur][i][2], v[cur][i][3])};
                     *reinterpret_cast<u32x2*>(&xs[(RPI * (b0 + i) + lrow) * LD + lcol]) = w;
                 }
                 __builtin_amdgcn_sched_barrier(0);
