@@ -95,6 +95,7 @@ struct CondActs {
     bool sqx = false;          // projection-free single-query T2I attention, generic kernel
     bool share0 = false;       // dropout replicas share the layer-0 input x0 and its QKV projection (no replicated copy)
     bool i2t_shared = false;   // I2T keys / values (projected text tokens) exist once for all replicas (many text tokens)
+    bool i2t_t1 = false;       // one text token: the I2T attention is its value projection (see cond_forward)
     bool sqx2 = false;         // ... streaming kernels with the per-head projections hoisted into batched GEMMs
     float *i2t_q, *i2t_kv, *i2t_P, *i2t_ctx, *i2t_out;
     float* c;     // [R*B, E]
@@ -921,7 +922,21 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     }
     GG_TRY(lin_fwd(c, a.t2i_ctx, E, w + n.t2i.ow, E, w + n.t2i.ob, a.t2i_out, E, (int)RB, E, E));
     // I2T: query = that vector, keys = values = encoded text tokens (R:220)
-    GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
+    // One text token (the headline shape): the softmax over a single key is 1 whatever the query, so the attention output is
+    // that token's value projection - exactly, gradients included (d softmax = 0: the query projection, the key projection
+    // and everything upstream of the query receive exactly zero from this block).  The query projection, the score kernel
+    // and, in the backward, their four gradient products are skipped; a padded single token still yields NaN as torch's
+    // softmax over one masked key does (k_sum2_nan_rows below).
+    static const bool no_t1 = getenv("GG_NO_I2T_T1") != nullptr;
+    const bool t1 = T == 1 && !a.i2t_shared && !no_t1;
+    a.i2t_t1 = t1;
+    if (!t1) GG_TRY(lin_fwd(c, a.t2i_out, E, w + n.i2t.inw, E, w + n.i2t.inb, a.i2t_q, E, (int)RB, E, E));
+    if (t1) {        // only V is needed: rows [2E, 3E) of in_proj, into the V half of i2t_kv
+        GG_TRY(lin_fwd(c, tok, E, w + n.i2t.inw + 2L * E * E, E, w + n.i2t.inb + 2 * E, a.i2t_kv + E, 2 * E, (int)RB, E, E));
+        GG_TRY(lin_fwd(c, a.i2t_kv + E, 2 * E, w + n.i2t.ow, E, w + n.i2t.ob, a.i2t_out, E, (int)RB, E, E));
+        KL(k_sum2_nan_rows(a.c, a.t2i_out, a.i2t_out, in->text_pad, RB, B, E, c.st));
+        return 0;
+    }
     if (a.i2t_shared) {
         TlinP t;
         t.X = a.tok; t.ldx = E; t.M = (long)B * T; t.W = WB(n, n.i2t.inw + (long)E * E); t.ldw = E; t.bias = w + n.i2t.inb + E;
@@ -1008,6 +1023,26 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         KL(k_copy_rows_strided_bcast(e->sdx, (long)S * E, dc, E, RB, RB, E, c.st));
     } else {
     // ---- I2T backward: t = out_proj(ctx); scores over text tokens; q from p -----------------------
+    if (a.i2t_t1) {
+        // ctx = V(token): d(ctx) goes straight to the V half; dq = dk = 0 exactly, so p's gradient is dc alone
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, dc, E, a.i2t_kv + E, 2 * E, g + n.i2t.ow, E, (int)RB, E, E));
+            GG_TRY(k_colsum(dc, RB, E, E, g + n.i2t.ob, cs.st)); e->launches++;
+            GG_TRY(side_end(c, fk, 3));
+        }
+        GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_dkv2 + E, 2 * E, (int)RB, E, E));      // d(V rows), ld 2E
+        KL(k_copy(e->s_dp, dc, RB * E, c.st));                                                      // c = t + p
+        {
+            Ctx cs = c;
+            const bool fk = side_begin(c, cs);
+            GG_TRY(lin_bwd_weight(cs, e->s_dkv2 + E, 2 * E, tok, E, g + n.i2t.inw + 2L * E * E, E, (int)RB, E, E));
+            GG_TRY(k_colsum(e->s_dkv2 + E, RB, E, 2 * E, g + n.i2t.inb + 2 * E, cs.st)); e->launches++;
+            GG_TRY(side_end(c, fk, 3));
+        }
+        GG_TRY(lin_bwd_data(c, e->s_dkv2 + E, 2 * E, w + n.i2t.inw + 2L * E * E, E, e->s_dtokrep, E, (int)RB, E, E));
+    } else {
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;
         const bool fk = side_begin(c, cs);
@@ -1046,6 +1081,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     } else {
         GG_TRY(lin_bwd_data(c, e->s_dkv2, 2 * E, w + n.i2t.inw + (long)E * E, E, e->s_dtokrep, E, (int)(RB * T), 2 * E, E));
     }
+    }   // !i2t_t1
     // ---- T2I backward ---------------------------------------------------------------------------------
     {   // parameter-gradient leaves: side stream (see side_begin)
         Ctx cs = c;

@@ -94,6 +94,8 @@ int k_fold_rows_add(float* dst, long ldd, const float* src, long B, int R, int c
 int k_fold(float* out, const float* in, long n, int R, hipStream_t st);
 // out[(b*P+p), :] = seq[b, 1+p, :]   (drop the CLS row: [B,P+1,E] -> [B*P,E])
 int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st);
+// c = a + b row-wise ([rows, E]); rows of samples (row % B) with pad[b] != 0 become NaN
+int k_sum2_nan_rows(float* c, const float* a, const float* b, const uint8_t* pad, long rows, int B, int E, hipStream_t st);
 // demb [B*(S-1), E] = patch rows, cls_rows [B, E] = CLS rows of the sum over the R replicas of dx [R, B, S, E]
 int k_fold_gather(float* demb, float* cls_rows, const float* dx, int B, int S, int E, int R, hipStream_t st);
 // the inverse: seq[b, 1+p, :] = in[(b*P+p), :]

@@ -1113,6 +1113,19 @@ int k_fold_gather(float* demb, float* cls_rows, const float* dx, int B, int S, i
     fold_gather_k<<<nblocks((long)B * S * E / 4, TPB, 16384), TPB, 0, st>>>(demb, cls_rows, dx, B, S, E, R);
     GG_LAUNCH_CHECK();
 }
+// c[r, :] = a[r, :] + b[r, :], or NaN for the rows whose sample (r % B) has pad[b] set (a softmax over one masked key)
+__global__ void sum2_nan_rows_k(float* __restrict__ c, const float* __restrict__ a, const float* __restrict__ b,
+                                const uint8_t* __restrict__ pad, long rows, int B, int E) {
+    const long n = rows * E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / E;
+        c[i] = (pad && pad[r % B]) ? __builtin_nanf("") : a[i] + b[i];
+    }
+}
+int k_sum2_nan_rows(float* c, const float* a, const float* b, const uint8_t* pad, long rows, int B, int E, hipStream_t st) {
+    sum2_nan_rows_k<<<nblocks(rows * E, TPB, 4096), TPB, 0, st>>>(c, a, b, pad, rows, B, E);
+    GG_LAUNCH_CHECK();
+}
 int k_gather_patch_rows(float* out, const float* seq, int B, int P, int E, hipStream_t st) {
     gather_patch_rows_k<<<nblocks((long)B * P * E, TPB, 16384), TPB, 0, st>>>(out, seq, B, P, E);
     GG_LAUNCH_CHECK();
