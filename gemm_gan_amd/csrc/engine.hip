@@ -654,13 +654,13 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
-            static const char* extra[15] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
+            static const char* extra[16] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
                                             "wst_ln_kernel<8,2,16,false,2>", "wst_ln_kernel<8,2,16,true,3>", "wst_ln_kernel<4,2,16,true,2>",
                                             "wst_ln_kernel<8,1,48,true,1>",
                                             "tlin_res16_kernel<8,256,true,1,true>", "tlin_str_kernel<256,false,true,0,true>",
                                             "tlin_str_kernel<256,false,true,1,true>", "wst_ln_kernel<4,2,16,true,0,true>",
                                             "wst_ln_kernel<8,1,32,true,0,true>", "wst_ln_kernel<8,2,16,false,2,true>",
-                                            "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>"};
+                                            "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>", "wst_ln_kernel<4,1,48,true,1,false,2>"};
             if (kc >= 32) snprintf(nm, sizeof nm, "%s", extra[kc - 32]);
             else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);

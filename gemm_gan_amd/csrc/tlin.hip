@@ -982,7 +982,7 @@ bool wst_routed(const TlinP& p) {
 }
 // classes >= 32: kernels outside the tlin_str_kernel<256, XB, YB, EPI> family (engine.hip try_tlin names them)
 int tlin_kernel_class(const TlinP& p) {
-    if (wst_routed(p)) return wst_ln_supported(p) ? (p.K == 256 ? 32 : 33) : (wst_kind(p) == 6 ? 46 : 33 + wst_kind(p));      // 32 .. 38, 46
+    if (wst_routed(p)) return wst_ln_supported(p) ? (p.K == 256 ? 32 : 33) : (wst_kind(p) >= 6 ? 40 + wst_kind(p) : 33 + wst_kind(p));      // 32 .. 38, 46
     if (p.fp8) {
         static const bool no_wst8 = getenv("GG_NO_WST") != nullptr || getenv("GG_NO_WST8") != nullptr;
         if (!no_wst8 && wst_fp8_kind(p)) return 41 + wst_fp8_kind(p);        // 42 .. 45

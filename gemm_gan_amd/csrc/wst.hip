@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // token-tile owner, each stationary on its own N rows of W and streaming the SAME tiles; the block index is decoded so that
 // the groups of one owner sit on one XCD (ids that differ by multiples of 8) and re-read the tile from that XCD's L2.
 template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
-__global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
     const int grp = GROUPS > 1 ? (int)(blockIdx.x >> 3) % GROUPS : 0;
     const long owner = GROUPS > 1 ? (long)(blockIdx.x / (8 * GROUPS)) * 8 + (blockIdx.x & 7) : (long)blockIdx.x;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
                 for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(resp + 32 * rt + 4 * g);
         }
         if constexpr (EPI == EPI_ACC) {
-            const float* yo = reinterpret_cast<const float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h;
+            const float* yo = reinterpret_cast<const float*>(p.Y) + (long)tokc * p.ldy + gcol + f0 + 16 * h;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
                     v += bb;
                     if constexpr (EPI == EPI_ACC) {
                         v += res[rt][g];
-                        if (valid) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h + 32 * rt + 4 * g) = v;
+                        if (valid) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)tokc * p.ldy + gcol + f0 + 16 * h + 32 * rt + 4 * g) = v;
                     }
                     if constexpr (EPI == EPI_ACT) {
                         if (p.act_relu) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wst_ln_kernel(const TlinP p) {
 
 template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
 int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    static_assert(GROUPS == 1 || (EPI == EPI_ACT && !F8), "column groups: plain bf16-output epilogue only");
+    static_assert(GROUPS == 1 || ((EPI == EPI_ACT || EPI == EPI_ACC) && !F8), "column groups: the plain epilogues only");
     constexpr int K = 16 * KS, N = 32 * NW * RT;
     constexpr size_t smem = (size_t)2 * TT * (F8 ? K + 16 : (K + 8) * 2) + (size_t)2 * NW * TT * 2 * 4 + (size_t)3 * N * 4;
     static bool attr_set = false;
@@ -338,7 +338,7 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         attr_set = true;
     }
     const long ntiles = (p.M + TT - 1) / TT;
-    const long slots = (long)n_cu * (NW == 4 ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8
+    const long slots = (long)n_cu * ((NW == 4 && KS < 48) ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8 (or with the K = 768 tile)
     unsigned grid = (unsigned)std::min<long>(ntiles, slots);
     if (GROUPS > 1) {       // owners in whole groups of 8 (one per XCD), GROUPS workgroups each
         const long owners = std::max<long>(8, std::min<long>((ntiles + 7) / 8 * 8, slots / GROUPS / 8 * 8));
@@ -375,6 +375,7 @@ int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
 //   4  y (bf16) = act(X W^T + b), N = 256, K = 256, bf16 X              (dctx = dres Wo)
 //   5  as 1 with K = 768                                                 (dx += dqkv Win)
 //   6  y (bf16) = X W^T + b, N = 768 = 3 column groups of 256, K = 256, fp32 X   (packed QKV projection, forward)
+//   7  as 5 (K = 768) as 2 column groups of 128                          (dx += dqkv Win)
 int wst_kind(const TlinP& p) {
     if (p.fp8 || p.ln_g || p.res || p.film_g || p.y_row_group || p.M < 1) return 0;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 8 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
@@ -382,6 +383,12 @@ int wst_kind(const TlinP& p) {
     // K = 768 (dx += dqkv Win) has an instantiation (case 5) but its 192 weight registers leave no room: 172 B of spills per
     // lane, 1.96 ms against 1.67 ms for the token-on-lane kernel at cfg3 - it stays there
     static const bool k768 = getenv("GG_WST_K768") != nullptr;
+    // K = 768 (dx += dqkv Win): two column groups of 128 per token-tile owner, 4 waves with 192 weight registers each at one
+    // wave per SIMD (no spills: 256 VGPRs + 103 AGPRs) - 1.66 -> 1.22 ms per step against the token-on-lane kernel, 4.25 TB/s
+    static const bool k768g = getenv("GG_NO_WST_K768G") == nullptr;
+    if (k768g && p.accumulate && !p.mask_ref && !p.act_relu && !p.y_bf16 && p.x_bf16 && p.N == 256 && p.K == 768 && p.drop.p == 0.f && !p.bias &&
+        p.ldy % 4 == 0)
+        return 7;
     if (p.accumulate && !p.mask_ref && !p.act_relu && !p.y_bf16 && p.x_bf16 && p.N == 256 && (p.K == 512 || (k768 && p.K == 768)) &&
         p.drop.p == 0.f && !p.bias && p.ldy % 4 == 0)
         return p.K == 512 ? 1 : 5;
@@ -428,6 +435,7 @@ int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         case 4: return launch<4, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
         case 5: return launch<8, 1, 48, true, EPI_ACC>(p, st, ev0, ev1);
         case 6: return launch<4, 2, 16, false, EPI_ACT, false, 3>(p, st, ev0, ev1);
+        case 7: return launch<4, 1, 48, true, EPI_ACC, false, 2>(p, st, ev0, ev1);
     }
     set_error("wst_other: no instantiation for this call");
     return -2;
