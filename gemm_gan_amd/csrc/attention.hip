@@ -377,6 +377,276 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Row-major-only variants (round 2).  The kernels above keep a TRANSPOSED copy of V (forward) / K (dQ) in LDS for the
+// "accumulator tile as B operand" product; gfx950's transposing LDS read (frag_tr_rows below, the dK/dV kernel's idiom) takes
+// that fragment out of the ROW-MAJOR image instead.  What that buys:
+//   * one staging pass less, all of it 16-byte coalesced loads, and EVERY load of the workgroup - K, V, the mask and the first
+//     query tile - is in flight before the first LDS write: one global round trip per workgroup where the kernels above made
+//     nine (forward) to twenty (dQ) serialised ones (43 % / 62 % of their wave time was spent waiting on memory);
+//   * only the rows up to S rounded to 8 are staged (reads of the last key tile are clamped onto a zero row), so K + V of
+//     S = 257 / dh = 64 take 76 KB: two workgroups per CU without chunking the keys in the dQ kernel;
+//   * NW = 8 waves per workgroup: four waves per SIMD hide the LDS / MFMA / exp latencies of each other.
+// Arithmetic, accumulation order inside a (query tile, key tile) pair and the dropout stream are those of the kernels above.
+// ------------------------------------------------------------------------------------------------------
+typedef short s16x4r __attribute__((ext_vector_type(4)));
+// transposed A fragment out of a row-major image: element j of lane (c, h) = img[min(row0 + 16*s2 + 8*(j>>2) + 4*h + (j&3), rlim)][col0 + c]
+__device__ __forceinline__ bf16x8 frag_tr_rows(const __bf16* img, int ld, int row0, int rlim, int col0, int s2, int lane) {
+    const int i = lane & 15, grp = lane >> 4;
+    const int hh = grp >> 1, colhalf = grp & 1;
+    const int ra = row0 + 16 * s2 + 4 * hh + (i >> 2);
+    const int co = col0 + 16 * colhalf + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) s16x4r lds_s16x4;
+    const s16x4r a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + min(ra, rlim) * ld + co));
+    const s16x4r b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + min(ra + 8, rlim) * ld + co));
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+// K and V row-major images of R = ceil8(S) rows (rows >= S zero): all loads of a pass in flight before its first LDS write.
+// `mid` runs once, uniformly in every thread, between the first pass's loads and its LDS writes: work that consumes OTHER loads
+// issued earlier (the key flags) goes there, so that it does not put a wait in front of these loads.
+template <int DH, bool IOB, int NT, int U, typename F>
+__device__ __forceinline__ void stage_two_rows(__bf16* As, __bf16* Bs, const void* XA, long aoff, long lda, const void* XB, long boff, long ldb,
+                                               int S, int R, int tid, F&& mid) {
+    constexpr int LD = DH + 8, CPR = DH / 8;
+    const int nchunk = R * CPR;
+    const int rmax = max(S - 1, 0);
+    for (int c0 = 0; c0 < nchunk; c0 += U * NT) {          // uniform trip count
+        bf16x8 aw[U], bw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = min(c0 + tid + u * NT, nchunk - 1);
+            const long row = min(cc / CPR, rmax);
+            aw[u] = load_frag8<IOB>(XA, aoff + row * lda + 8 * (cc % CPR));
+            bw[u] = load_frag8<IOB>(XB, boff + row * ldb + 8 * (cc % CPR));
+        }
+        if (c0 == 0) mid();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c0 + tid + u * NT;
+            if (cc < nchunk) {
+                const int row = cc / CPR, c8 = cc % CPR;
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<bf16x8*>(As + row * LD + 8 * c8) = row < S ? aw[u] : z;
+                *reinterpret_cast<bf16x8*>(Bs + row * LD + 8 * c8) = row < S ? bw[u] : z;
+            }
+        }
+    }
+}
+template <int DH, bool IOB, int NT, int U, typename F>
+__device__ __forceinline__ void stage_kv_rows(__bf16* Ks, __bf16* Vs, const void* X, long koff, long voff, long ldx, int S, int R, int tid, F&& mid) {
+    stage_two_rows<DH, IOB, NT, U>(Ks, Vs, X, koff, ldx, X, voff, ldx, S, R, tid, mid);
+}
+// Key flags Ms[Sp] (1 = masked or past the end) and per-tile "any flag" Mt (one ballot per 64 keys).  The mask bytes of the
+// first MASK_U * NT keys are loaded by mask_request (unconditionally, clamped) and consumed by mask_flags later.
+constexpr int MASK_U = 2;
+template <int NT>
+__device__ __forceinline__ void mask_request(uint8_t (&mf)[MASK_U], const uint8_t* mask, long moff, int S, int tid) {
+#pragma unroll
+    for (int u = 0; u < MASK_U; ++u) mf[u] = mask ? mask[moff + min(tid + u * NT, max(S - 1, 0))] : (uint8_t)0;
+}
+template <int NT>
+__device__ __forceinline__ void mask_flags(uint8_t* Ms, uint8_t* Mt, const uint8_t (&mf)[MASK_U], const uint8_t* mask, long moff, int S, int Sp, int tid) {
+    for (int u = 0; u * NT < Sp; ++u) {                    // uniform trip count
+        const int i = u * NT + tid;
+        uint8_t f = 0;
+        if (u < MASK_U) f = u == 0 ? mf[0] : mf[1];
+        else if (i < S && mask) f = mask[moff + i];
+        if (i >= S) f = i < Sp ? 1 : 0;
+        if (i < Sp) Ms[i] = f;
+        const uint64_t b = __builtin_amdgcn_ballot_w64(f != 0);
+        if ((tid & 31) == 0 && i < Sp) Mt[i >> 5] = (tid & 32) ? ((b >> 32) != 0) : ((uint32_t)b != 0);
+    }
+}
+
+template <int DH, bool IOB, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                                  int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
+                                                                  int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 64 * NW;
+    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    constexpr int LDK = DH + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vs = Ks + R * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + R * LDK);
+    uint8_t* Mt = Ms + Sp;
+    float* Co = reinterpret_cast<float*>(Mt + 64);        // [waves 1..NW-1][CO_MAXQ][DH + 2] partials of the shared query tile
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const bool coop = (nqt % NW == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;      // workgroup-uniform
+    const int nq_main = coop ? nqt - 1 : nqt;
+    const int n_items = nq_main + (coop ? NW : 0);
+
+    // the query fragments of a wave's NEXT tile are requested before the current one is multiplied
+    bf16x8 qn[KS];
+    auto request = [&](int it) {
+        const int qt = it >= nq_main ? nqt - 1 : it;
+        const int qc = min(qt * 32 + c, S - 1);        // rows past the end re-read the last query: never stored
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qn[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+    };
+    if (wave < n_items) request(wave);
+    const long moff = (long)(n % mask_B) * S;
+    uint8_t mf[MASK_U];
+    mask_request<NT>(mf, mask, moff, S, tid);
+    stage_kv_rows<DH, IOB, NT, (NW == 8 ? 5 : 9)>(Ks, Vs, qkv, base + E, base + 2 * E, ld, S, R, tid,
+                                                   [&]() { mask_flags<NT>(Ms, Mt, mf, mask, moff, S, Sp, tid); });
+    __syncthreads();
+
+    const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (int it = wave; it < n_items; it += NW) {
+        const bool shared = it >= nq_main;             // the left-over tile: every wave passes here exactly once
+        const int qt = shared ? nqt - 1 : it;
+        const int kt0 = shared ? wave : 0, kstep = shared ? NW : 1;
+        const int q = qt * 32 + c;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = qn[s];
+        if (it + NW < n_items) request(it + NW);
+        float m = -INFINITY, l = 0.f;
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+        for (int kt = kt0; kt < nkt; kt += kstep) {
+            f32x16 s16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s16[i] = 0.f;
+            const __bf16* krow = Ks + min(kt * 32 + c, R - 1) * LDK + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            } else {                    // tile without masked keys: no per-element mask lookups
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s16[i] *= sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const bool move = mt > m + 8.f;            // lazy reference update, as in attn_fwd_kernel
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const float mn = move ? mt : m;
+                const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);
+                l *= alpha;
+                m = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            }
+            const float mref = (m == -INFINITY) ? 0.f : m;
+            float lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = fast_exp2(s16[i] - mref);
+                lt += p;
+                s16[i] = p;
+            }
+            lt += __shfl_xor(lt, 32, 64);
+            l += lt;
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    s16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? s16[4 * g + 0] : 0.f;
+                    s16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? s16[4 * g + 1] : 0.f;
+                    s16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? s16[4 * g + 2] : 0.f;
+                    s16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? s16[4 * g + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = frag_tr_rows(Vs, LDK, kt * 32, R - 1, dt * 32, s2, lane);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (shared) {      // merge the NW key-range partials of the shared tile (softmax-weighted) in wave 0
+            if (wave != 0 && q < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
+                if (h == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) part[2 + d] = O[dt][i];
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (q < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (DH + 2);
+                constexpr int WS = CO_MAXQ * (DH + 2);
+                float M = m;
+#pragma unroll
+                for (int w = 0; w < NW - 1; ++w) M = fmaxf(M, p0[w * WS]);
+                const float mref = (M == -INFINITY) ? 0.f : M;
+                const float w0 = fast_exp2(m - mref);
+                l *= w0;
+                m = M;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= w0;
+#pragma unroll 1
+                for (int w = 0; w < NW - 1; ++w) {          // one partial at a time: 32 LDS values in flight, not 32 * (NW - 1)
+                    const float wgt = fast_exp2(p0[w * WS] - mref);
+                    l += p0[w * WS + 1] * wgt;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) O[dt][i] += p0[w * WS + 2 + min(dt * 32 + acc_row(i, h), DH - 1)] * wgt;
+                }
+            }
+        }
+        if (q < S) {
+            const float inv = ks / l;
+            const long out = ((long)n * S + q) * E + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv};
+                        store4<IOB>(ctx, out + d, v);
+                    }
+                }
+            if (h == 0) lse2[(long)blockIdx.x * S + q] = m + log2f(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // forward, long sequences (S above the LDS-resident range of attn_fwd_kernel, e.g. 1 025 patch tokens): grid.y splits
 // the query tiles four at a time (one per wave) and the keys stream through LDS in chunks of CK; the online softmax
 // state of a wave's query tile lives in registers across the chunks.  Same arithmetic and dropout stream as above.
@@ -916,6 +1186,195 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const void* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, dQ, row-major-only variant (see attn_fwd_rm_kernel): K and V row-major, the K^T operand of dQ^T = K^T dS^T through
+// the transposing LDS read.  All keys resident (two workgroups per CU at S = 257 / dh = 64), so a query tile's Q / dO / O
+// rows are read once; with PF the next tile's rows are requested while the current one is multiplied.
+// ------------------------------------------------------------------------------------------------------
+template <int DH, bool IOB, int NW, bool PF>
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const void* __restrict__ qkv, const void* __restrict__ ctx,
+                                                                     const void* __restrict__ dctx,
+                                                                     const float* __restrict__ lse2, float* __restrict__ delta,
+                                                                     const uint8_t* __restrict__ mask, int mask_B,
+                                                                     void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 64 * NW;
+    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    constexpr int LDK = DH + 8;
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vs = Ks + R * LDK;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + R * LDK);
+    uint8_t* Mt = Ms + Sp;
+    float* Co = reinterpret_cast<float*>(Mt + 64);
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const bool coop = (nqt % NW == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;
+    const int nq_main = coop ? nqt - 1 : nqt;
+    const int n_items = nq_main + (coop ? NW : 0);
+
+    // one query tile's operands: Q and dO fragments, the O row pieces for delta = sum_d dO * O, the row's log-sum-exp
+    bf16x8 qn[KS], dn[KS];
+    float on[KS][8], dvn[KS][8];                       // fp32 I/O only: the bf16 route recovers dO from dn and keeps O packed
+    bf16x8 opk[KS];
+    float l2n = 0.f;
+    auto request = [&](int it) {
+        const int qt = it >= nq_main ? nqt - 1 : it;
+        const int qc = min(qt * 32 + c, S - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+            qn[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+            dn[s] = load_frag8<IOB>(dctx, off);
+            if constexpr (IOB) {
+                opk[s] = load_frag8<true>(ctx, off);
+            } else {
+                load_f32x8<false>(dctx, off, dvn[s]);
+                load_f32x8<false>(ctx, off, on[s]);
+            }
+        }
+        l2n = lse2[(long)blockIdx.x * S + qc];
+    };
+    auto delta_of_request = [&]() -> float {            // this lane-half's part of delta for the requested rows
+        float dl = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (IOB) {
+                const u32x4 dw = __builtin_bit_cast(u32x4, dn[s]), ow = __builtin_bit_cast(u32x4, opk[s]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dl += __builtin_bit_cast(float, dw[j] << 16) * __builtin_bit_cast(float, ow[j] << 16);
+                    dl += __builtin_bit_cast(float, dw[j] & 0xffff0000u) * __builtin_bit_cast(float, ow[j] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += dvn[s][j] * on[s][j];
+            }
+        }
+        return dl;
+    };
+    if (wave < n_items) request(wave);
+    const long moff = (long)(n % mask_B) * S;
+    uint8_t mf[MASK_U];
+    mask_request<NT>(mf, mask, moff, S, tid);
+    stage_kv_rows<DH, IOB, NT, (NW == 8 ? 5 : 9)>(Ks, Vs, qkv, base + E, base + 2 * E, ld, S, R, tid,
+                                                   [&]() { mask_flags<NT>(Ms, Mt, mf, mask, moff, S, Sp, tid); });
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (int it = wave; it < n_items; it += NW) {
+        const bool shared = it >= nq_main;
+        const int qt = shared ? nqt - 1 : it;
+        const int kt0 = shared ? wave : 0, kstep = shared ? NW : 1;
+        const int q = qt * 32 + c;
+        if (!PF && it != wave) request(it);
+        bf16x8 qf[KS], df[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { qf[s] = qn[s]; df[s] = dn[s]; }
+        float dl = delta_of_request();
+        const float L2 = q < S ? l2n : 0.f;
+        if (PF && it + NW < n_items) request(it + NW);
+        dl += __shfl_xor(dl, 32, 64);
+        if (q < S && h == 0 && (!shared || wave == 0)) delta[(long)blockIdx.x * S + q] = dl;      // consumed by the dK/dV kernel
+        f32x16 dQ[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+        const uint32_t srow = drop_state(drop, (((uint64_t)blockIdx.x * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+        for (int kt = kt0; kt < nkt; kt += kstep) {
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+            const int krow = min(kt * 32 + c, R - 1) * LDK + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow + 16 * s);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + krow + 16 * s);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+                dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
+            }
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                    dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                    dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                    dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
+                    s16[i] = p * (dp16[i] - dl) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(s16[i] * sc - L2) * (dp16[i] - dl) * scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 kf = frag_tr_rows(Ks, LDK, kt * 32, R - 1, dt * 32, s2, lane);
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (shared) {      // sum the NW key-range partials of the shared tile in wave 0
+            if (wave != 0 && q < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) part[d] = dQ[dt][i];
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (q < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (DH + 2);
+                constexpr int WS = CO_MAXQ * (DH + 2);
+#pragma unroll 1
+                for (int w = 0; w < NW - 1; ++w)             // one partial at a time (register pressure)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) dQ[dt][i] += p0[w * WS + min(dt * 32 + acc_row(i, h), DH - 1)];
+            }
+        }
+        if (q < S) {
+            const long out = ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {dQ[dt][4 * g], dQ[dt][4 * g + 1], dQ[dt][4 * g + 2], dQ[dt][4 * g + 3]};
+                        store4<IOB>(dqkv, out + d, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, dQ, long sequences: attn_bwd_dq2_kernel's scheme with a run-time number of key chunks of CK keys and grid.y
 // over groups of 4 * DQ_SLOTS query tiles (no shared left-over tile: every tile belongs to one wave).
 // ------------------------------------------------------------------------------------------------------
@@ -1269,6 +1728,204 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const void* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// backward, dK / dV, workgroup-resident variant (see attn_fwd_rm_kernel).  The kernel above gives every WAVE its own key tile
+// and has it fetch all nqt query tiles (Q, dO, lse, delta) from global memory into a private LDS slab: nkt x the traffic, one
+// global round trip and two LDS writes per tile step.  Here one workgroup owns a (sample, head): Q and dO row-major, lse and
+// delta are staged ONCE (one round trip, ceil8(S) rows), the waves take key tiles round-robin with K / V fragments in
+// registers (the next tile's requested while the current one is multiplied), and the row-major A fragments of S = Q K^T,
+// dP = dO V^T and the transposed ones of dV^T += dO^T P, dK^T += Q^T dS all come out of the same two images: no LDS writes,
+// no barriers inside the loop.  A left-over key tile of at most CO_MAXQ keys (S = 257) is shared: every wave takes every
+// NW-th query tile for it and the partial dK / dV rows are summed through LDS.
+// Arithmetic and dropout stream as above.
+// ------------------------------------------------------------------------------------------------------
+template <int DH, bool IOB, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const void* __restrict__ qkv, const void* __restrict__ dctx,
+                                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                          const uint8_t* __restrict__ mask, int mask_B,
+                                                                          void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 64 * NW;
+    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    constexpr int LDK = DH + 8;
+    __bf16* Qs = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Ds = Qs + R * LDK;
+    float* Ls = reinterpret_cast<float*>(Ds + R * LDK);
+    float* Dl = Ls + Sp;
+    float* Co = Dl + Sp;                                   // [waves 1..NW-1][CO_MAXQ][2 * DH]
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const long nhid = blockIdx.x;
+    const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const long dbase = (long)n * S * E + hd * DH;
+    const long moff = (long)(n % mask_B) * S;
+    const int nqt = Sp / 32, nkt = Sp / 32;
+    const bool coop = (nkt % NW == 1) && nkt > 1 && (S - 32 * (nkt - 1)) <= CO_MAXQ;
+    const int nk_main = coop ? nkt - 1 : nkt;
+    const int n_items = nk_main + (coop ? NW : 0);
+
+    bf16x8 kn[KS], vn[KS];
+    uint8_t mkn = 0;
+    auto request_kv = [&](int it) {
+        const int kt = it >= nk_main ? nkt - 1 : it;
+        const int keyc = min(kt * 32 + c, S - 1);          // keys past the end re-read the last key: masked below, never stored
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kn[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + E + 16 * s + 8 * h);
+            vn[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + 2 * E + 16 * s + 8 * h);
+        }
+        mkn = mask ? mask[moff + keyc] : (uint8_t)0;
+    };
+    if (wave < n_items) request_kv(wave);
+    stage_two_rows<DH, IOB, NT, (NW == 8 ? 5 : 9)>(Qs, Ds, qkv, base, ld, dctx, dbase, (long)E, S, R, tid, [&]() {
+        for (int u = 0; u * NT < Sp; ++u) {
+            const int i = u * NT + tid;
+            const int ic = min(i, S - 1);
+            const float a = lse2[nhid * S + ic], b = delta[nhid * S + ic];
+            if (i < Sp) {
+                Ls[i] = i < S ? a : 0.f;
+                Dl[i] = i < S ? b : 0.f;
+            }
+        }
+    });
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int par = c & 1;
+    const uint32_t Sd = (uint32_t)drop_attn_ld(S);
+    const uint32_t rowmul = (Sd / 2) * DROP_PHI;
+    const int shl = par ? 0 : 16;                      // odd element -> high half, even element -> low half
+    const uint32_t thr_hi = drop.thr << 16;
+    for (int it = wave; it < n_items; it += NW) {
+        const bool shared = it >= nk_main;
+        const int kt = shared ? nkt - 1 : it;
+        const int qt0 = shared ? wave : 0, qstep = shared ? NW : 1;
+        const int key = kt * 32 + c;
+        const bool kvalid = key < S && !mkn;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
+        if (it + NW < n_items) request_kv(it + NW);
+        f32x16 dK[DT], dV[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
+        // dropout stream constants of this lane (drop_rng.h): pair state of (row 0 of tile 0, this key), row step, parity
+        const uint32_t stile = drop_state(drop, (((uint64_t)nhid * S) * Sd) / 2 + (uint64_t)(key >> 1)) + (uint32_t)(par + 4 * h) * rowmul;
+        for (int qt = qt0; qt < nqt; qt += qstep) {
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+            const int qrow = min(qt * 32 + c, R - 1) * LDK + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + qrow + 16 * s);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Ds + qrow + 16 * s);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], s16, 0, 0, 0);
+                dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp16, 0, 0, 0);
+            }
+            // rows 8g + 4h .. +3 of the tile (registers 4g .. 4g+3): log-sum-exp and delta as two 16-byte LDS reads per group
+            f32x4 lsv[4], dlv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lsv[g] = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * h]);
+                dlv[g] = *reinterpret_cast<const f32x4*>(&Dl[qt * 32 + 8 * g + 4 * h]);
+            }
+            uint32_t bits[16];
+            if (drop.p > 0.f) {      // each lane hashes the rows of its own parity and takes the other 8 from its neighbour (see above)
+                const uint32_t st = stile + (uint32_t)(qt * 32) * rowmul;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t mine = drop_bits(st + (uint32_t)(2 * (k & 1) + 8 * (k >> 1)) * rowmul);      // row of register 2k + par
+                    const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                    bits[2 * k] = par ? theirs : mine;
+                    bits[2 * k + 1] = par ? mine : theirs;
+                }
+            }
+            const bool rows_full = qt * 32 + 32 <= S;
+            f32x16 pd16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = fast_exp2(s16[i] * sc - lsv[i >> 2][i & 3]);
+                float pk = p, dpk = dp16[i];
+                if (drop.p > 0.f) {
+                    const bool keep = (bits[i] << shl) >= thr_hi;
+                    pk = keep ? p * ks : 0.f;
+                    dpk = keep ? dpk * ks : 0.f;
+                }
+                float ds = p * (dpk - dlv[i >> 2][i & 3]) * scale;
+                const bool ok = kvalid && (rows_full || qt * 32 + acc_row(i, h) < S);
+                pd16[i] = ok ? pk : 0.f;
+                s16[i] = ok ? ds : 0.f;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(pd16, s2);
+                const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 dof = frag_tr_rows(Ds, LDK, qt * 32, R - 1, dt * 32, s2, lane);
+                    const bf16x8 qtf = frag_tr_rows(Qs, LDK, qt * 32, R - 1, dt * 32, s2, lane);
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (shared) {      // sum the NW query-range partials of the shared key tile in wave 0
+            constexpr int WS = CO_MAXQ * 2 * DH;
+            if (wave != 0 && key < S) {
+                float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (2 * DH);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int d = dt * 32 + acc_row(i, h);
+                        if (d < DH) { part[d] = dK[dt][i]; part[DH + d] = dV[dt][i]; }
+                    }
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+            if (key < S) {
+                const float* p0 = Co + min(c, CO_MAXQ - 1) * (2 * DH);
+#pragma unroll 1
+                for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int d = min(dt * 32 + acc_row(i, h), DH - 1);
+                            dK[dt][i] += p0[w * WS + d];
+                            dV[dt][i] += p0[w * WS + DH + d];
+                        }
+            }
+        }
+        if (key < S) {
+            const long outk = ((long)n * S + key) * ld + E + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 a = {dK[dt][4 * g], dK[dt][4 * g + 1], dK[dt][4 * g + 2], dK[dt][4 * g + 3]};
+                        f32x4 b = {dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2], dV[dt][4 * g + 3]};
+                        store4<IOB>(dqkv, outk + d, a);
+                        store4<IOB>(dqkv, outk + E + d, b);
+                    }
+                }
+        }
+    }
+}
+
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
     return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
@@ -1276,6 +1933,24 @@ size_t fwd_smem(int S, int DH) {
 size_t dq_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
     return (size_t)2 * Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
+}
+
+size_t rm_smem(int S, int DH, int NW) {          // attn_fwd_rm_kernel / attn_bwd_dq_rm_kernel: K and V row-major, ceil8(S) rows
+    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    return (size_t)2 * R * (DH + 8) * 2 + Sp + 64 + 16 + (size_t)(NW - 1) * CO_MAXQ * (DH + 2) * 4;
+}
+size_t dkv_rm_smem(int S, int DH, int NW) {
+    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    return (size_t)2 * R * (DH + 8) * 2 + (size_t)2 * Sp * 4 + (size_t)(NW - 1) * CO_MAXQ * 2 * DH * 4;
+}
+// waves per workgroup of the row-major kernels, 0 = off (GG_ATTN_V1).  Measured at S = 257 / dh = 64 / B = 256 (tools/attn_ab.sh):
+// forward 155 us (kernels above) -> 146 us (4 waves) -> 132 us (8 waves, 128 registers); dQ 211 us -> 135 us (4 waves with the
+// next-tile request) - the 8-wave dQ kernel needs more than its 128 registers and spills (208 us).
+int rm_waves(bool fwd) {
+    static const bool off = getenv("GG_ATTN_V1") != nullptr;
+    static const int nwf = [] { const char* e = getenv("GG_ATTN_FWD_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
+    static const int nwd = [] { const char* e = getenv("GG_ATTN_DQ_NW"); return e && atoi(e) == 8 ? 8 : 4; }();
+    return off ? 0 : (fwd ? nwf : nwd);
 }
 
 size_t dq2_smem(int S, int DH) {
@@ -1326,9 +2001,18 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
     const size_t sm = lng ? fwd_long_smem(S, dh, ck) : fwd_smem(S, dh);
     const int nqg = ((S + 31) / 32 + 3) / 4;                  // long kernels: query groups of four tiles
     const dim3 grid(lng ? (unsigned)(((N * nh + 7) / 8) * 8 * nqg) : (unsigned)(N * nh));
+    const int nw = rm_waves(true);
+    const bool rm = !lng && nw && rm_smem(S, dh, nw) <= 160 * 1024;
+    const size_t smr = rm ? rm_smem(S, dh, nw) : 0;
 #define GG_FWD(D, B)                                                                                          \
     do {                                                                                                      \
-        if (lng) {                                                                                            \
+        if (rm && nw == 8) {                                                                                  \
+            GG_TRY(set_smem(&attn_fwd_rm_kernel<D, B, 8>, smr));                                              \
+            hipLaunchKernelGGL((attn_fwd_rm_kernel<D, B, 8>), grid, dim3(512), smr, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
+        } else if (rm) {                                                                                      \
+            GG_TRY(set_smem(&attn_fwd_rm_kernel<D, B, 4>, smr));                                              \
+            hipLaunchKernelGGL((attn_fwd_rm_kernel<D, B, 4>), grid, dim3(256), smr, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
+        } else if (lng) {                                                                                            \
             GG_TRY(set_smem(&attn_fwd_long_kernel<D, B>, sm));                                                \
             hipLaunchKernelGGL((attn_fwd_long_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, ck, (int)(N * nh), nqg); \
         } else {                                                                                              \
@@ -1371,9 +2055,24 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     const size_t sml = lng ? dq_long_smem(S, dh, ck) : 0;
     const int nqgl = (nqt_ + 4 * DQ_SLOTS - 1) / (4 * DQ_SLOTS);
     const dim3 gridl((unsigned)(((N * nh + 7) / 8) * 8 * nqgl));
+    const int nw = rm_waves(false);
+    const bool rm = !lng && nw && rm_smem(S, dh, nw) <= 160 * 1024;
+    const size_t smr = rm ? rm_smem(S, dh, nw) : 0;
+    static const bool dkv_v1 = getenv("GG_ATTN_DKV_V1") != nullptr;
+    const size_t smk = dkv_rm_smem(S, dh, 4);
+    const bool rmk = !lng && nw && !dkv_v1 && 2 * smk <= 160 * 1024;      // worth it only with two workgroups per CU
+#define GG_BWD_RM(D, B, NW_, PF_)                                                                                           \
+    do {                                                                                                                    \
+        GG_TRY(set_smem(&attn_bwd_dq_rm_kernel<D, B, NW_, PF_>, smr));                                                      \
+        hipLaunchKernelGGL((attn_bwd_dq_rm_kernel<D, B, NW_, PF_>), grid, dim3(64 * NW_), smr, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+    } while (0)
 #define GG_BWD(D, B)                                                                                                        \
     do {                                                                                                                    \
-        if (lng) {                                                                                                          \
+        if (rm && nw == 8) {                                                                                         \
+            GG_BWD_RM(D, B, 8, false);                                                                                      \
+        } else if (rm) {                                                                                                    \
+            GG_BWD_RM(D, B, 4, true);                                                                                       \
+        } else if (lng) {                                                                                                          \
             GG_TRY(set_smem(&attn_bwd_dq_long_kernel<D, B>, sml));                                                          \
             hipLaunchKernelGGL((attn_bwd_dq_long_kernel<D, B>), gridl, dim3(256), sml, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, ck, (int)(N * nh), nqgl); \
         } else if (use_dq2) {                                                                                                      \
@@ -1384,7 +2083,12 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
         }                                                                                                                   \
         if (ev_mid) GG_CHECK_HIP(hipEventRecord(ev_mid, st));   /* profiling: splits the pair into its two kernels */ \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items, qB); \
+        if (rmk) {                                                                                                          \
+            GG_TRY(set_smem(&attn_bwd_dkv_rm_kernel<D, B, 4>, smk));                                                        \
+            hipLaunchKernelGGL((attn_bwd_dkv_rm_kernel<D, B, 4>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, B>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, items, qB); \
+        }                                                                                                                   \
     } while (0)
     if (io_bf16) {
         if (dh == 64) GG_BWD(64, true);
@@ -1396,6 +2100,7 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
         else GG_BWD(16, false);
     }
 #undef GG_BWD
+#undef GG_BWD_RM
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
