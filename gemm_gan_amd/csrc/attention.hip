@@ -389,12 +389,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
 // Arithmetic, accumulation order inside a (query tile, key tile) pair and the dropout stream are those of the kernels above.
 // ------------------------------------------------------------------------------------------------------
 typedef short s16x4r __attribute__((ext_vector_type(4)));
-// transposed A fragment out of a row-major image: element j of lane (c, h) = img[min(row0 + 16*s2 + 8*(j>>2) + 4*h + (j&3), rlim)][col0 + c]
+// rows staged by the row-major kernels: S rounded up so that - unless S is a multiple of 32 - at least ONE zero row follows the
+// data (row R - 1 >= S).  Reads of the last 32-row tile are clamped onto that row: finite for the operands that meet a zero
+// probability anyway (K, V rows past the end) and exactly zero where the dK/dV kernel relies on it (Q, dO rows past the end).
+__host__ __device__ __forceinline__ int rm_rows(int S) {
+    const int Sp = (S + 31) / 32 * 32, r = (S + 8) / 8 * 8;
+    return r < Sp ? r : Sp;
+}
+// Per-lane LDS element offsets of one 32-row tile's reads, computed once per kernel: the four transposing reads
+// (element j of lane (c, h) of fragment s2 = img[row0 + 16*s2 + 8*(j>>2) + 4*h + (j&3)][col0 + c]) and the row-major fragment row
+// (row0 + c, column 8*h).  Per tile they cost one add each; only a tile that reaches past the staged rows takes the clamping path
+// (wave-uniform branch).  The address arithmetic used to be a fifth of the VALU work of a tile step.
+struct TileOff {
+    int tr[4], rm;             // [2*s2 + b]: rows 16*s2 + 8*b + 4*hh + (i>>2); rm: row c
+    int ld, rlim;              // uniform
+    __device__ __forceinline__ void init(int ld_, int rlim_, int lane) {
+        const int i = lane & 15, grp = lane >> 4;
+        ld = ld_; rlim = rlim_;
+        const int rr = 4 * (grp >> 1) + (i >> 2), co = 16 * (grp & 1) + 4 * (i & 3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tr[k] = (rr + 8 * k) * ld + co;
+        rm = (lane & 31) * ld + 8 * (lane >> 5);
+    }
+    __device__ __forceinline__ void tile(int row0, int lane, int (&t)[4], int& r) const {
+        if (row0 + 31 > rlim) {        // the lane-derived pieces are recomputed here rather than kept in registers
+            const int i = lane & 15, grp = lane >> 4;
+            const int rr = 4 * (grp >> 1) + (i >> 2), co = 16 * (grp & 1) + 4 * (i & 3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = min(row0 + rr + 8 * k, rlim) * ld + co;
+            r = min(row0 + (lane & 31), rlim) * ld + 8 * (lane >> 5);
+        } else {
+            const int o = row0 * ld;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = tr[k] + o;
+            r = rm + o;
+        }
+    }
+};
+__device__ __forceinline__ bf16x8 frag_tr_at(const __bf16* img, const int (&t)[4], int s2, int col0) {
+    typedef __attribute__((address_space(3))) s16x4r lds_s16x4;
+    const s16x4r a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + t[2 * s2] + col0));
+    const s16x4r b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + t[2 * s2 + 1] + col0));
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+// the same fragment with the addresses computed in place (no registers held across tiles: the 8-wave forward kernel has none to spare)
 __device__ __forceinline__ bf16x8 frag_tr_rows(const __bf16* img, int ld, int row0, int rlim, int col0, int s2, int lane) {
     const int i = lane & 15, grp = lane >> 4;
-    const int hh = grp >> 1, colhalf = grp & 1;
-    const int ra = row0 + 16 * s2 + 4 * hh + (i >> 2);
-    const int co = col0 + 16 * colhalf + 4 * (i & 3);
+    const int ra = row0 + 16 * s2 + 4 * (grp >> 1) + (i >> 2);
+    const int co = col0 + 16 * (grp & 1) + 4 * (i & 3);
     typedef __attribute__((address_space(3))) s16x4r lds_s16x4;
     const s16x4r a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + min(ra, rlim) * ld + co));
     const s16x4r b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + min(ra + 8, rlim) * ld + co));
@@ -467,7 +512,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
     const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
-    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     constexpr int LDK = DH + 8;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vs = Ks + R * LDK;
@@ -478,7 +523,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
     constexpr int KS = DH / 16;
 
     const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile loops and their branches run on the SALU
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
     const long base = (long)(n % qkv_B) * S * ld + hd * DH;
@@ -503,8 +549,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
                                                    [&]() { mask_flags<NT>(Ms, Mt, mf, mask, moff, S, Sp, tid); });
     __syncthreads();
 
-    const float sc = rsqrtf((float)DH) * LOG2E;     // applied to the fp32 scores after the MFMA
+    const float sc = rsqrtf((float)DH) * LOG2E;     // folded into the exponent's multiply-add
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    constexpr bool TOFF = NW < 8;                   // precomputed tile offsets cost five registers
+    TileOff toff;
+    if constexpr (TOFF) toff.init(LDK, R - 1, lane);
     for (int it = wave; it < n_items; it += NW) {
         const bool shared = it >= nq_main;             // the left-over tile: every wave passes here exactly once
         const int qt = shared ? nqt - 1 : it;
@@ -525,28 +574,32 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
             f32x16 s16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s16[i] = 0.f;
-            const __bf16* krow = Ks + min(kt * 32 + c, R - 1) * LDK + 8 * h;
+            int tro[4], kro;
+            if constexpr (TOFF) toff.tile(kt * 32, lane, tro, kro);
+            else kro = min(kt * 32 + c, R - 1) * LDK + 8 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kro + 16 * s);
                 s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
             }
+            // TOFF variants: maximum of the RAW scores (the scale is positive), the scale itself rides in the exponent's multiply-add
             float mt = -INFINITY;
             if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kt * 32 + acc_row(i, h);
-                    s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
+                    s16[i] = Ms[key] ? -INFINITY : (TOFF ? s16[i] : s16[i] * sc);
                     mt = fmaxf(mt, s16[i]);
                 }
             } else {                    // tile without masked keys: no per-element mask lookups
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    s16[i] *= sc;
+                    if constexpr (!TOFF) s16[i] *= sc;
                     mt = fmaxf(mt, s16[i]);
                 }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            if constexpr (TOFF) mt *= sc;
             const bool move = mt > m + 8.f;            // lazy reference update, as in attn_fwd_kernel
             if (__builtin_amdgcn_ballot_w64(move) != 0) {
                 const float mn = move ? mt : m;
@@ -558,11 +611,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
 #pragma unroll
                     for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
             }
-            const float mref = (m == -INFINITY) ? 0.f : m;
+            const float nmref = (m == -INFINITY) ? 0.f : -m;
             float lt = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = fast_exp2(s16[i] - mref);
+                const float p = TOFF ? fast_exp2(__builtin_fmaf(s16[i], sc, nmref)) : fast_exp2(s16[i] + nmref);
                 lt += p;
                 s16[i] = p;
             }
@@ -584,7 +637,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_rm_kernel(const void
                 const bf16x8 pf = frag_from_acc(s16, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 vf = frag_tr_rows(Vs, LDK, kt * 32, R - 1, dt * 32, s2, lane);
+                    const bf16x8 vf = TOFF ? frag_tr_at(Vs, tro, s2, dt * 32) : frag_tr_rows(Vs, LDK, kt * 32, R - 1, dt * 32, s2, lane);
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[dt], 0, 0, 0);
                 }
             }
@@ -1199,7 +1252,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const v
     const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
-    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     constexpr int LDK = DH + 8;
     __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Vs = Ks + R * LDK;
@@ -1210,7 +1263,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const v
     constexpr int KS = DH / 16;
 
     const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile loops and their branches run on the SALU
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
     const long base = (long)(n % qkv_B) * S * ld + hd * DH;
@@ -1270,6 +1324,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const v
     const float scale = rsqrtf((float)DH);
     const float sc = scale * LOG2E;
     const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    TileOff toff;
+    toff.init(LDK, R - 1, lane);
     for (int it = wave; it < n_items; it += NW) {
         const bool shared = it >= nq_main;
         const int qt = shared ? nqt - 1 : it;
@@ -1294,7 +1350,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const v
             f32x16 s16, dp16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
-            const int krow = min(kt * 32 + c, R - 1) * LDK + 8 * h;
+            int tro[4], krow;
+            toff.tile(kt * 32, lane, tro, krow);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow + 16 * s);
@@ -1313,27 +1370,32 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dq_rm_kernel(const v
                     dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
                 }
             }
+            // dS without the 1 / sqrt(dh) factor: it multiplies the finished dQ tile once instead of every element of every tile
             if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kt * 32 + acc_row(i, h);
-                    const float p = Ms[key] ? 0.f : fast_exp2(s16[i] * sc - L2);
-                    s16[i] = p * (dp16[i] - dl) * scale;
+                    const float p = Ms[key] ? 0.f : fast_exp2(__builtin_fmaf(s16[i], sc, -L2));
+                    s16[i] = p * (dp16[i] - dl);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(s16[i] * sc - L2) * (dp16[i] - dl) * scale;
+                for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(__builtin_fmaf(s16[i], sc, -L2)) * (dp16[i] - dl);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 sf = frag_from_acc(s16, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 kf = frag_tr_rows(Ks, LDK, kt * 32, R - 1, dt * 32, s2, lane);
+                    const bf16x8 kf = frag_tr_at(Ks, tro, s2, dt * 32);
                     dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[dt], 0, 0, 0);
                 }
             }
         }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[dt][i] *= scale;
         if (shared) {      // sum the NW key-range partials of the shared tile in wave 0
             if (wave != 0 && q < S) {
                 float* part = Co + ((wave - 1) * CO_MAXQ + min(c, CO_MAXQ - 1)) * (DH + 2);
@@ -1747,7 +1809,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
     const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
-    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     constexpr int LDK = DH + 8;
     __bf16* Qs = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* Ds = Qs + R * LDK;
@@ -1759,7 +1821,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
 
     const long nhid = blockIdx.x;
     const int n = blockIdx.x / nh, hd = blockIdx.x % nh;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tile loops and their branches run on the SALU
     const int c = lane & 31, h = lane >> 5;
     const long ld = 3L * E;
     const long base = (long)(n % qkv_B) * S * ld + hd * DH;
@@ -1804,6 +1867,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
     const uint32_t rowmul = (Sd / 2) * DROP_PHI;
     const int shl = par ? 0 : 16;                      // odd element -> high half, even element -> low half
     const uint32_t thr_hi = drop.thr << 16;
+    TileOff toff;
+    toff.init(LDK, R - 1, lane);
     for (int it = wave; it < n_items; it += NW) {
         const bool shared = it >= nk_main;
         const int kt = shared ? nkt - 1 : it;
@@ -1821,11 +1886,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
             for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
         // dropout stream constants of this lane (drop_rng.h): pair state of (row 0 of tile 0, this key), row step, parity
         const uint32_t stile = drop_state(drop, (((uint64_t)nhid * S) * Sd) / 2 + (uint64_t)(key >> 1)) + (uint32_t)(par + 4 * h) * rowmul;
+        // No validity selects inside the loop:
+        //  * query rows past the end are ZERO rows of Q and dO (rm_rows) with lse = delta = 0: p = 1, dP = 0, dS = p (0 - 0) = 0, and
+        //    dV^T += dO^T P sees a zero row of dO - both contributions vanish by themselves;
+        //  * a masked / padded key is one LANE's column of dK^T, dV^T: it is zeroed once, after the loop;
+        //  * 1 / sqrt(dh) multiplies the finished dK tile once.
         for (int qt = qt0; qt < nqt; qt += qstep) {
             f32x16 s16, dp16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
-            const int qrow = min(qt * 32 + c, R - 1) * LDK + 8 * h;
+            int tro[4], qrow;
+            toff.tile(qt * 32, lane, tro, qrow);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + qrow + 16 * s);
@@ -1840,32 +1911,32 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
                 lsv[g] = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * h]);
                 dlv[g] = *reinterpret_cast<const f32x4*>(&Dl[qt * 32 + 8 * g + 4 * h]);
             }
-            uint32_t bits[16];
-            if (drop.p > 0.f) {      // each lane hashes the rows of its own parity and takes the other 8 from its neighbour (see above)
+            f32x16 pd16;
+            if (drop.p > 0.f) {
+                // Each lane hashes the rows of its own parity (register 2k + par); the even lane's word then serves register 2k of
+                // BOTH lanes of the pair and the odd lane's word register 2k + 1: two DPP broadcasts, no per-lane selects.
                 const uint32_t st = stile + (uint32_t)(qt * 32) * rowmul;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const uint32_t mine = drop_bits(st + (uint32_t)(2 * (k & 1) + 8 * (k >> 1)) * rowmul);      // row of register 2k + par
-                    const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-                    bits[2 * k] = par ? theirs : mine;
-                    bits[2 * k + 1] = par ? mine : theirs;
-                }
-            }
-            const bool rows_full = qt * 32 + 32 <= S;
-            f32x16 pd16;
+                    const uint32_t mine = drop_bits(st + (uint32_t)(2 * (k & 1) + 8 * (k >> 1)) * rowmul);
+                    const uint32_t be = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xA0, 0xf, 0xf, true);   // quad_perm [0,0,2,2]
+                    const uint32_t bo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xF5, 0xf, 0xf, true);   // quad_perm [1,1,3,3]
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = fast_exp2(s16[i] * sc - lsv[i >> 2][i & 3]);
-                float pk = p, dpk = dp16[i];
-                if (drop.p > 0.f) {
-                    const bool keep = (bits[i] << shl) >= thr_hi;
-                    pk = keep ? p * ks : 0.f;
-                    dpk = keep ? dpk * ks : 0.f;
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * k + e;
+                        const float km = ((e ? bo : be) << shl) >= thr_hi ? ks : 0.f;
+                        const float p = fast_exp2(__builtin_fmaf(s16[i], sc, -lsv[i >> 2][i & 3]));
+                        pd16[i] = p * km;
+                        s16[i] = p * __builtin_fmaf(dp16[i], km, -dlv[i >> 2][i & 3]);
+                    }
                 }
-                float ds = p * (dpk - dlv[i >> 2][i & 3]) * scale;
-                const bool ok = kvalid && (rows_full || qt * 32 + acc_row(i, h) < S);
-                pd16[i] = ok ? pk : 0.f;
-                s16[i] = ok ? ds : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(__builtin_fmaf(s16[i], sc, -lsv[i >> 2][i & 3]));
+                    pd16[i] = p;
+                    s16[i] = p * (dp16[i] - dlv[i >> 2][i & 3]);
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -1873,12 +1944,19 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
                 const bf16x8 sf = frag_from_acc(s16, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 dof = frag_tr_rows(Ds, LDK, qt * 32, R - 1, dt * 32, s2, lane);
-                    const bf16x8 qtf = frag_tr_rows(Qs, LDK, qt * 32, R - 1, dt * 32, s2, lane);
+                    const bf16x8 dof = frag_tr_at(Ds, tro, s2, dt * 32);
+                    const bf16x8 qtf = frag_tr_at(Qs, tro, s2, dt * 32);
                     dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
                     dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
                 }
             }
+        }
+        {
+            const float kz = kvalid ? scale : 0.f, vz = kvalid ? 1.f : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { dK[dt][i] *= kz; dV[dt][i] *= vz; }
         }
         if (shared) {      // sum the NW query-range partials of the shared key tile in wave 0
             constexpr int WS = CO_MAXQ * 2 * DH;
@@ -1936,11 +2014,11 @@ size_t dq_smem(int S, int DH) {
 }
 
 size_t rm_smem(int S, int DH, int NW) {          // attn_fwd_rm_kernel / attn_bwd_dq_rm_kernel: K and V row-major, ceil8(S) rows
-    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     return (size_t)2 * R * (DH + 8) * 2 + Sp + 64 + 16 + (size_t)(NW - 1) * CO_MAXQ * (DH + 2) * 4;
 }
 size_t dkv_rm_smem(int S, int DH, int NW) {
-    const int Sp = (S + 31) / 32 * 32, R = (S + 7) / 8 * 8;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     return (size_t)2 * R * (DH + 8) * 2 + (size_t)2 * Sp * 4 + (size_t)(NW - 1) * CO_MAXQ * 2 * DH * 4;
 }
 // waves per workgroup of the row-major kernels, 0 = off (GG_ATTN_V1).  Measured at S = 257 / dh = 64 / B = 256 (tools/attn_ab.sh):
