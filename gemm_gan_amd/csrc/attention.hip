@@ -856,6 +856,227 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const void* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Long sequences, row-major streaming variants (round 2).  The *_long kernels above stage every key chunk with several
+// serialised global round trips between two barriers and give a wave ONE query tile: at S = 1 025 they ran 4 - 5x above the
+// VALU time of their tile steps (image-transformer config: 45 of 84 ms per step).  Here
+//   * chunks of CK = 128 rows of two row-major operands (K and V; Q and dO in the dK/dV kernel) travel global -> registers ->
+//     one of TWO LDS buffers: chunk c + 2 is requested and chunk c + 1 written to the other buffer BEFORE chunk c is multiplied,
+//     so a chunk's loads have a whole chunk of MFMA / softmax work to land and there is one barrier per chunk;
+//   * a wave owns QT = 2 tiles of the resident side (query tiles in forward / dQ, key tiles in dK/dV): 8 tiles per workgroup
+//     halve the number of passes over the streamed operands, and every LDS fragment feeds two MFMAs;
+//   * transposed operands through ds_read_b64_tr_b16, tile offsets precomputed, wave index scalar (see the *_rm kernels).
+// Same arithmetic and dropout stream as the kernels above.
+// ------------------------------------------------------------------------------------------------------
+constexpr int SCK = 128;                                    // streamed rows per chunk
+constexpr int SQT = 2;                                      // resident tiles per wave
+// registers of one chunk in flight: SCK rows x DH columns of two operands over 256 threads
+template <int DH, bool IOB, int CK = SCK, int NT = 256>
+struct ChunkRegs {
+    static constexpr int CPR = DH / 8, NP = CK * CPR / NT > 0 ? CK * CPR / NT : 1;
+    bf16x8 a[NP], b[NP];
+    // rows [row0, row0 + SCK) of A (XA + aoff, stride lda) and B; rows >= S are clamped for the load and zero-filled by store()
+    __device__ __forceinline__ void load(const void* XA, long aoff, long lda, const void* XB, long boff, long ldb, int row0, int S, int tid) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = min(tid + NT * u, CK * CPR - 1);
+            const long row = min(row0 + p / CPR, S - 1);
+            a[u] = load_frag8<IOB>(XA, aoff + row * lda + 8 * (p % CPR));
+            b[u] = load_frag8<IOB>(XB, boff + row * ldb + 8 * (p % CPR));
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* As, __bf16* Bs, int row0, int S, int tid) const {
+        constexpr int LD = DH + 8;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = tid + NT * u;
+            if (p < CK * CPR) {
+                const int row = p / CPR, c8 = p % CPR;
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<bf16x8*>(As + row * LD + 8 * c8) = row0 + row < S ? a[u] : z;
+                *reinterpret_cast<bf16x8*>(Bs + row * LD + 8 * c8) = row0 + row < S ? b[u] : z;
+            }
+        }
+    }
+};
+size_t stream_smem(int S, int DH) {                         // two buffers x two operands + key flags (forward / dQ)
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)4 * SCK * (DH + 8) * 2 + Sp + 64 + 16;
+}
+
+template <int DH, bool IOB, int NW, int QT>
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_fwd_stream_kernel(const void* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                                 int mask_B, void* __restrict__ ctx, float* __restrict__ lse2,
+                                                                 int S, int E, int nh, DropKey drop_in, int qkv_B, int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = SCK * LDK;
+    __bf16* Kb = reinterpret_cast<__bf16*>(smem_raw);           // [2][IMG]
+    __bf16* Vb = Kb + 2 * IMG;                                  // [2][IMG]
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vb + 2 * IMG);
+    uint8_t* Mt = Ms + Sp;
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    // XCD-aware order (see attn_fwd_long_kernel): the query groups of one (sample, head) pair share an XCD's L2
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const long moff = (long)(n % mask_B) * S;
+    const int nkt = Sp / 32;
+    const int nchunks = (R + SCK - 1) / SCK;
+
+    // this wave's query tiles: NW * QT * qg + wave + NW * j (tiles past the end recompute the last row and store nothing)
+    bf16x8 qf[QT][KS];
+    int q[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        q[j] = (NW * QT * qg + wave + NW * j) * 32 + c;
+        const int qc = min(q[j], S - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[j][s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+    }
+    uint8_t mf[MASK_U];
+    mask_request<64 * NW>(mf, mask, moff, S, tid);
+    ChunkRegs<DH, IOB, SCK, 64 * NW> cr;
+    cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, 0, S, tid);
+    mask_flags<64 * NW>(Ms, Mt, mf, mask, moff, S, Sp, tid);
+    cr.store(Kb, Vb, 0, S, tid);
+    if (nchunks > 1) cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, SCK, S, tid);
+    __syncthreads();
+
+    const float sc = rsqrtf((float)DH) * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    float m[QT], l[QT];
+    f32x16 O[QT][DT];
+    uint32_t srow[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        m[j] = -INFINITY; l[j] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[j][dt][i] = 0.f;
+        srow[j] = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q[j]) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+    }
+    TileOff toff;
+    toff.init(LDK, SCK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) cr.store(Kb + (buf ^ 1) * IMG, Vb + (buf ^ 1) * IMG, (ch + 1) * SCK, S, tid);
+        if (ch + 2 < nchunks) cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, (ch + 2) * SCK, S, tid);
+        const __bf16* Ks = Kb + buf * IMG;
+        const __bf16* Vs = Vb + buf * IMG;
+        toff.rlim = min(SCK, R - ch * SCK) - 1;
+        const int kt_end = min(nkt, (ch + 1) * (SCK / 32));
+        for (int kt = ch * (SCK / 32); kt < kt_end; ++kt) {
+            int tro[4], kro;
+            toff.tile((kt - ch * (SCK / 32)) * 32, lane, tro, kro);
+            f32x16 s16[QT];
+#pragma unroll
+            for (int j = 0; j < QT; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[j][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kro + 16 * s);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) s16[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j][s], s16[j], 0, 0, 0);
+            }
+            const bool masked = __builtin_amdgcn_readfirstlane((int)Mt[kt]) != 0;
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                float mt = -INFINITY;
+                if (masked) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt * 32 + acc_row(i, h);
+                        s16[j][i] = Ms[key] ? -INFINITY : s16[j][i] * sc;
+                        mt = fmaxf(mt, s16[j][i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s16[j][i] *= sc;
+                        mt = fmaxf(mt, s16[j][i]);
+                    }
+                }
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const bool move = mt > m[j] + 8.f;         // lazy reference update, as in attn_fwd_kernel
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float mn = move ? mt : m[j];
+                    const float alpha = (m[j] == -INFINITY) ? 0.f : fast_exp2(m[j] - mn);
+                    l[j] *= alpha;
+                    m[j] = mn;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) O[j][dt][i] *= alpha;
+                }
+                const float mref = (m[j] == -INFINITY) ? 0.f : m[j];
+                float lt = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(s16[j][i] - mref);
+                    lt += p;
+                    s16[j][i] = p;
+                }
+                lt += __shfl_xor(lt, 32, 64);
+                l[j] += lt;
+                if (drop.p > 0.f) {
+                    const uint32_t skt = srow[j] + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                        s16[j][4 * g + 0] = drop_keep_even(b0, drop.thr) ? s16[j][4 * g + 0] : 0.f;
+                        s16[j][4 * g + 1] = drop_keep_odd(b0, drop.thr) ? s16[j][4 * g + 1] : 0.f;
+                        s16[j][4 * g + 2] = drop_keep_even(b1, drop.thr) ? s16[j][4 * g + 2] : 0.f;
+                        s16[j][4 * g + 3] = drop_keep_odd(b1, drop.thr) ? s16[j][4 * g + 3] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf[QT];
+#pragma unroll
+                for (int j = 0; j < QT; ++j) pf[j] = frag_from_acc(s16[j], s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = frag_tr_at(Vs, tro, s2, dt * 32);
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) O[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j], O[j][dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        if (q[j] < S) {
+            const float inv = ks / l[j];
+            const long out = ((long)n * S + q[j]) * E + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    if (d < DH) {
+                        f32x4 v = {O[j][dt][4 * g] * inv, O[j][dt][4 * g + 1] * inv, O[j][dt][4 * g + 2] * inv, O[j][dt][4 * g + 3] * inv};
+                        store4<IOB>(ctx, out + d, v);
+                    }
+                }
+            if (h == 0) lse2[(long)pair * S + q[j]] = m[j] + log2f(l[j]);
+        }
+    }
+}
+
 // delta[n,h,q] = sum_d dO[n,q,h*DH+d] * O[n,q,h*DH+d]
 __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta,
                                   long rows, int S, int E, int nh) {
@@ -2004,6 +2225,319 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_dkv_rm_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// backward, long sequences, streaming row-major variants (see attn_fwd_stream_kernel).  One resident tile per wave (the dQ /
+// dK + dV accumulators and both operand fragment sets leave no room for two), four per workgroup.
+// dQ: the wave's query tile with Q, dO fragments, lse and delta in registers; K and V chunks stream.
+// ------------------------------------------------------------------------------------------------------
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream_kernel(const void* __restrict__ qkv, const void* __restrict__ ctx,
+                                                                    const void* __restrict__ dctx,
+                                                                    const float* __restrict__ lse2, float* __restrict__ delta,
+                                                                    const uint8_t* __restrict__ mask, int mask_B,
+                                                                    void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B,
+                                                                    int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = SCK * LDK;
+    __bf16* Kb = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* Vb = Kb + 2 * IMG;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vb + 2 * IMG);
+    uint8_t* Mt = Ms + Sp;
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const long moff = (long)(n % mask_B) * S;
+    const int nkt = Sp / 32;
+    const int nchunks = (R + SCK - 1) / SCK;
+
+    const int q = (4 * qg + wave) * 32 + c;
+    const int qc = min(q, S - 1);
+    bf16x8 qf[KS], df[KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+        qf[s] = load_frag8<IOB>(qkv, base + (long)qc * ld + 16 * s + 8 * h);
+        df[s] = load_frag8<IOB>(dctx, off);
+        float dv[8], ov[8];
+        load_f32x8<IOB>(dctx, off, dv);
+        load_f32x8<IOB>(ctx, off, ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += dv[j] * ov[j];
+    }
+    const float L2raw = lse2[(long)pair * S + qc];
+    uint8_t mf[MASK_U];
+    mask_request<256>(mf, mask, moff, S, tid);
+    ChunkRegs<DH, IOB> cr;
+    cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, 0, S, tid);
+    mask_flags<256>(Ms, Mt, mf, mask, moff, S, Sp, tid);
+    cr.store(Kb, Vb, 0, S, tid);
+    if (nchunks > 1) cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, SCK, S, tid);
+    dl += __shfl_xor(dl, 32, 64);
+    if (q < S && h == 0) delta[(long)pair * S + q] = dl;      // consumed by the dK/dV kernel
+    const float L2 = q < S ? L2raw : 0.f;
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    f32x16 dQ[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+    const uint32_t srow = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+    TileOff toff;
+    toff.init(LDK, SCK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) cr.store(Kb + (buf ^ 1) * IMG, Vb + (buf ^ 1) * IMG, (ch + 1) * SCK, S, tid);
+        if (ch + 2 < nchunks) cr.load(qkv, base + E, ld, qkv, base + 2 * E, ld, (ch + 2) * SCK, S, tid);
+        const __bf16* Ks = Kb + buf * IMG;
+        const __bf16* Vs = Vb + buf * IMG;
+        toff.rlim = min(SCK, R - ch * SCK) - 1;
+        const int kt_end = min(nkt, (ch + 1) * (SCK / 32));
+        for (int kt = ch * (SCK / 32); kt < kt_end; ++kt) {
+            int tro[4], krow;
+            toff.tile((kt - ch * (SCK / 32)) * 32, lane, tro, krow);
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow + 16 * s);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + krow + 16 * s);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s16, 0, 0, 0);
+                dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], dp16, 0, 0, 0);
+            }
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                    dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                    dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                    dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    const float p = Ms[key] ? 0.f : fast_exp2(__builtin_fmaf(s16[i], sc, -L2));
+                    s16[i] = p * (dp16[i] - dl);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[i] = fast_exp2(__builtin_fmaf(s16[i], sc, -L2)) * (dp16[i] - dl);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 kf = frag_tr_at(Ks, tro, s2, dt * 32);
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, dQ[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q < S) {
+        const long out = ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 v = {dQ[dt][4 * g] * scale, dQ[dt][4 * g + 1] * scale, dQ[dt][4 * g + 2] * scale, dQ[dt][4 * g + 3] * scale};
+                    store4<IOB>(dqkv, out + d, v);
+                }
+            }
+    }
+}
+
+// dK / dV: the wave's key tile with K, V fragments in registers; Q and dO chunks (with their lse / delta rows) stream.
+constexpr int DCK = 64;                                     // dK/dV: 64-row chunks (16 registers in flight: the kernel has no more to spare)
+size_t dkv_stream_smem(int DH) { return (size_t)4 * DCK * (DH + 8) * 2 + (size_t)4 * DCK * 4; }
+template <int DH, bool IOB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream_kernel(const void* __restrict__ qkv, const void* __restrict__ dctx,
+                                                                     const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                     const uint8_t* __restrict__ mask, int mask_B,
+                                                                     void* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B,
+                                                                     int npairs, int nkg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = DCK * LDK;
+    __bf16* Qb = reinterpret_cast<__bf16*>(smem_raw);           // [2][IMG]
+    __bf16* Db = Qb + 2 * IMG;                                  // [2][IMG]
+    float* Lb = reinterpret_cast<float*>(Db + 2 * IMG);         // [2][DCK] log-sum-exp rows of the chunk
+    float* Eb = Lb + 2 * DCK;                                   // [2][DCK] delta rows
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int KS = DH / 16;
+
+    const int pair = ((int)(blockIdx.x >> 3) / nkg) * 8 + (int)(blockIdx.x & 7);
+    const int kg = (int)(blockIdx.x >> 3) % nkg;
+    if (pair >= npairs) return;
+    const long nhid = pair;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const long base = (long)(n % qkv_B) * S * ld + hd * DH;
+    const long dbase = (long)n * S * E + hd * DH;
+    const int nqt = Sp / 32;
+    const int nchunks = (R + DCK - 1) / DCK;
+
+    const int key = (4 * kg + wave) * 32 + c;
+    const int keyc = min(key, S - 1);                  // keys past the end re-read the last key: zeroed below, never stored
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kf[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + E + 16 * s + 8 * h);
+        vf[s] = load_frag8<IOB>(qkv, base + (long)keyc * ld + 2 * E + 16 * s + 8 * h);
+    }
+    const uint8_t mk = mask ? mask[(long)(n % mask_B) * S + keyc] : (uint8_t)0;
+    ChunkRegs<DH, IOB, DCK> cr;
+    float lr = 0.f, er = 0.f;                          // this thread's lse / delta row of the chunk in flight (threads 0 .. DCK-1)
+    auto load_chunk = [&](int row0) {
+        cr.load(qkv, base, ld, dctx, dbase, (long)E, row0, S, tid);
+        const long r = nhid * S + min(row0 + (tid & (DCK - 1)), S - 1);
+        lr = lse2[r];
+        er = delta[r];
+    };
+    auto store_chunk = [&](int b, int row0) {
+        cr.store(Qb + b * IMG, Db + b * IMG, row0, S, tid);
+        if (tid < DCK) {
+            Lb[b * DCK + tid] = row0 + tid < S ? lr : 0.f;
+            Eb[b * DCK + tid] = row0 + tid < S ? er : 0.f;
+        }
+    };
+    load_chunk(0);
+    store_chunk(0, 0);
+    if (nchunks > 1) load_chunk(DCK);
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const int par = c & 1;
+    const uint32_t Sd = (uint32_t)drop_attn_ld(S);
+    const uint32_t rowmul = (Sd / 2) * DROP_PHI;
+    const int shl = par ? 0 : 16;
+    const uint32_t thr_hi = drop.thr << 16;
+    const uint32_t stile = drop_state(drop, (((uint64_t)nhid * S) * Sd) / 2 + (uint64_t)(key >> 1)) + (uint32_t)(par + 4 * h) * rowmul;
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
+    TileOff toff;
+    toff.init(LDK, DCK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1, (ch + 1) * DCK);
+        if (ch + 2 < nchunks) load_chunk((ch + 2) * DCK);
+        const __bf16* Qs = Qb + buf * IMG;
+        const __bf16* Ds = Db + buf * IMG;
+        const float* Ls = Lb + buf * DCK;
+        const float* Dl = Eb + buf * DCK;
+        toff.rlim = min(DCK, R - ch * DCK) - 1;
+        const int qt_end = min(nqt, (ch + 1) * (DCK / 32));
+        for (int qt = ch * (DCK / 32); qt < qt_end; ++qt) {       // see attn_bwd_dkv_rm_kernel: no validity selects in here
+            const int ql = (qt - ch * (DCK / 32)) * 32;
+            int tro[4], qrow;
+            toff.tile(ql, lane, tro, qrow);
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + qrow + 16 * s);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Ds + qrow + 16 * s);
+                s16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], s16, 0, 0, 0);
+                dp16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp16, 0, 0, 0);
+            }
+            f32x4 lsv[4], dlv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lsv[g] = *reinterpret_cast<const f32x4*>(&Ls[ql + 8 * g + 4 * h]);
+                dlv[g] = *reinterpret_cast<const f32x4*>(&Dl[ql + 8 * g + 4 * h]);
+            }
+            f32x16 pd16;
+            if (drop.p > 0.f) {
+                const uint32_t st = stile + (uint32_t)(qt * 32) * rowmul;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t mine = drop_bits(st + (uint32_t)(2 * (k & 1) + 8 * (k >> 1)) * rowmul);
+                    const uint32_t be = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xA0, 0xf, 0xf, true);   // quad_perm [0,0,2,2]
+                    const uint32_t bo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xF5, 0xf, 0xf, true);   // quad_perm [1,1,3,3]
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * k + e;
+                        const float km = ((e ? bo : be) << shl) >= thr_hi ? ks : 0.f;
+                        const float p = fast_exp2(__builtin_fmaf(s16[i], sc, -lsv[i >> 2][i & 3]));
+                        pd16[i] = p * km;
+                        s16[i] = p * __builtin_fmaf(dp16[i], km, -dlv[i >> 2][i & 3]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(__builtin_fmaf(s16[i], sc, -lsv[i >> 2][i & 3]));
+                    pd16[i] = p;
+                    s16[i] = p * (dp16[i] - dlv[i >> 2][i & 3]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(pd16, s2);
+                const bf16x8 sf = frag_from_acc(s16, s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 dof = frag_tr_at(Ds, tro, s2, dt * 32);
+                    const bf16x8 qtf = frag_tr_at(Qs, tro, s2, dt * 32);
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dV[dt], 0, 0, 0);
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sf, dK[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (key < S) {
+        const bool kvalid = !mk;
+        const float kz = kvalid ? scale : 0.f, vz = kvalid ? 1.f : 0.f;
+        const long outk = ((long)n * S + key) * ld + E + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 a = {dK[dt][4 * g] * kz, dK[dt][4 * g + 1] * kz, dK[dt][4 * g + 2] * kz, dK[dt][4 * g + 3] * kz};
+                    f32x4 b = {dV[dt][4 * g] * vz, dV[dt][4 * g + 1] * vz, dV[dt][4 * g + 2] * vz, dV[dt][4 * g + 3] * vz};
+                    store4<IOB>(dqkv, outk + d, a);
+                    store4<IOB>(dqkv, outk + E + d, b);
+                }
+            }
+    }
+}
+
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
     return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
@@ -2079,6 +2613,12 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
     const size_t sm = lng ? fwd_long_smem(S, dh, ck) : fwd_smem(S, dh);
     const int nqg = ((S + 31) / 32 + 3) / 4;                  // long kernels: query groups of four tiles
     const dim3 grid(lng ? (unsigned)(((N * nh + 7) / 8) * 8 * nqg) : (unsigned)(N * nh));
+    static const bool strm_off = getenv("GG_ATTN_LONG_V1") != nullptr;
+    const bool strm = lng && !strm_off;                         // streaming row-major kernel: 8 query tiles per workgroup (8 waves x 1 or 4 x 2)
+    static const bool strm8 = getenv("GG_ATTN_STREAM_NW4") == nullptr;
+    const size_t sms = stream_smem(S, dh);
+    const int nqgs = ((S + 31) / 32 + 4 * SQT - 1) / (4 * SQT);
+    const dim3 grids((unsigned)(((N * nh + 7) / 8) * 8 * nqgs));
     const int nw = rm_waves(true);
     const bool rm = !lng && nw && rm_smem(S, dh, nw) <= 160 * 1024;
     const size_t smr = rm ? rm_smem(S, dh, nw) : 0;
@@ -2090,6 +2630,14 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
         } else if (rm) {                                                                                      \
             GG_TRY(set_smem(&attn_fwd_rm_kernel<D, B, 4>, smr));                                              \
             hipLaunchKernelGGL((attn_fwd_rm_kernel<D, B, 4>), grid, dim3(256), smr, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB); \
+        } else if (lng && strm) {                                                                                    \
+            if (strm8) {                                                                                      \
+                GG_TRY(set_smem(&attn_fwd_stream_kernel<D, B, 8, 1>, sms));                                   \
+                hipLaunchKernelGGL((attn_fwd_stream_kernel<D, B, 8, 1>), grids, dim3(512), sms, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, (int)(N * nh), nqgs); \
+            } else {                                                                                          \
+                GG_TRY(set_smem(&attn_fwd_stream_kernel<D, B, 4, 2>, sms));                                   \
+                hipLaunchKernelGGL((attn_fwd_stream_kernel<D, B, 4, 2>), grids, dim3(256), sms, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, (int)(N * nh), nqgs); \
+            }                                                                                                 \
         } else if (lng) {                                                                                            \
             GG_TRY(set_smem(&attn_fwd_long_kernel<D, B>, sm));                                                \
             hipLaunchKernelGGL((attn_fwd_long_kernel<D, B>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, ck, (int)(N * nh), nqg); \
@@ -2133,6 +2681,12 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     const size_t sml = lng ? dq_long_smem(S, dh, ck) : 0;
     const int nqgl = (nqt_ + 4 * DQ_SLOTS - 1) / (4 * DQ_SLOTS);
     const dim3 gridl((unsigned)(((N * nh + 7) / 8) * 8 * nqgl));
+    static const bool strm_off = getenv("GG_ATTN_LONG_V1") != nullptr;
+    static const bool strm_dq = getenv("GG_ATTN_DQ_LONG_V1") == nullptr;
+    const bool strm = lng && !strm_off;                         // streaming row-major kernels: one query / key tile per wave, four per workgroup
+    const size_t sms = stream_smem(S, dh), smks = dkv_stream_smem(dh);
+    const int ngs = (nqt_ + 3) / 4;
+    const dim3 grids((unsigned)(((N * nh + 7) / 8) * 8 * ngs));
     const int nw = rm_waves(false);
     const bool rm = !lng && nw && rm_smem(S, dh, nw) <= 160 * 1024;
     const size_t smr = rm ? rm_smem(S, dh, nw) : 0;
@@ -2150,6 +2704,9 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
             GG_BWD_RM(D, B, 8, false);                                                                                      \
         } else if (rm) {                                                                                                    \
             GG_BWD_RM(D, B, 4, true);                                                                                       \
+        } else if (lng && strm && strm_dq) {                                                                                \
+            GG_TRY(set_smem(&attn_bwd_dq_stream_kernel<D, B>, sms));                                                        \
+            hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, B>), grids, dim3(256), sms, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ngs); \
         } else if (lng) {                                                                                                          \
             GG_TRY(set_smem(&attn_bwd_dq_long_kernel<D, B>, sml));                                                          \
             hipLaunchKernelGGL((attn_bwd_dq_long_kernel<D, B>), gridl, dim3(256), sml, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, ck, (int)(N * nh), nqgl); \
@@ -2161,7 +2718,10 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, B>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
         }                                                                                                                   \
         if (ev_mid) GG_CHECK_HIP(hipEventRecord(ev_mid, st));   /* profiling: splits the pair into its two kernels */ \
-        if (rmk) {                                                                                                          \
+        if (lng && strm) {                                                                                                  \
+            GG_TRY(set_smem(&attn_bwd_dkv_stream_kernel<D, B>, smks));                                                      \
+            hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, B>), grids, dim3(256), smks, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ngs); \
+        } else if (rmk) {                                                                                                   \
             GG_TRY(set_smem(&attn_bwd_dkv_rm_kernel<D, B, 4>, smk));                                                        \
             hipLaunchKernelGGL((attn_bwd_dkv_rm_kernel<D, B, 4>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB); \
         } else {                                                                                                            \
