@@ -2602,6 +2602,34 @@ bool flash_attn_supported(int S, int E, int nh) {
     return short_ok(S, dh) || S <= LONG_MAX_S;      // beyond the LDS-resident range: the key-streaming kernels
 }
 
+// Name of the kernel flash_attn_fwd (which = 0) / the dQ (1) / the dK/dV (2) half of flash_attn_bwd launches for this shape:
+// the profile classes of the engine and the PMC summaries are keyed by the kernels' own names.  Mirrors the dispatch below.
+const char* flash_attn_kernel_name(int which, int S, int E, int nh) {
+    if (!flash_attn_supported(S, E, nh)) return "";
+    const int dh = E / nh;
+    const bool lng = getenv("GG_ATTN_LONG") != nullptr || !short_ok(S, dh);
+    const bool strm = lng && getenv("GG_ATTN_LONG_V1") == nullptr;
+    const int nqt = (S + 31) / 32;
+    if (which == 0) {
+        const int nw = rm_waves(true);
+        if (!lng && nw && rm_smem(S, dh, nw) <= 160 * 1024) return "attn_fwd_rm_kernel";
+        return strm ? "attn_fwd_stream_kernel" : lng ? "attn_fwd_long_kernel" : "attn_fwd_kernel";
+    }
+    const int nw = rm_waves(false);
+    if (which == 1) {
+        if (!lng && nw && rm_smem(S, dh, nw) <= 160 * 1024) return "attn_bwd_dq_rm_kernel";
+        if (strm && getenv("GG_ATTN_DQ_LONG_V1") == nullptr) return "attn_bwd_dq_stream_kernel";
+        if (lng) return "attn_bwd_dq_long_kernel";
+        const bool coop = (nqt % 4 == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;
+        const int items_q = (coop ? nqt - 1 : nqt) + (coop ? 4 : 0);
+        const bool dq2 = getenv("GG_ATTN_DQ1") == nullptr && nqt >= 2 && items_q <= 4 * DQ_SLOTS && 2 * dq2_smem(S, dh) <= 160 * 1024;
+        return dq2 ? "attn_bwd_dq2_kernel" : "attn_bwd_dq_kernel";
+    }
+    if (strm) return "attn_bwd_dkv_stream_kernel";
+    if (!lng && nw && getenv("GG_ATTN_DKV_V1") == nullptr && 2 * dkv_rm_smem(S, dh, 4) <= 160 * 1024) return "attn_bwd_dkv_rm_kernel";
+    return "attn_bwd_dkv_kernel";
+}
+
 int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, long N, int S, int E, int nh,
                    DropKey drop, int io_bf16, hipStream_t st, long qkv_B) {
     const int qB = (int)(qkv_B > 0 ? qkv_B : N);

@@ -818,7 +818,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
         if (use_flash) {
             {   // algorithmic: packed QKV read once (B rows when layer 0 is shared by the replicas), context written once
                 const double tok = (double)RB * S, qtok = (share0 && l == 0 ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
-                ProfScope ps(c, "attn_fwd_kernel", 4.0 * tok * S * E, es * (3.0 * qtok * E + tok * E) + 4.0 * tok * nh);
+                ProfScope ps(c, flash_attn_kernel_name(0, S, E, nh), 4.0 * tok * S * E, es * (3.0 * qtok * E + tok * E) + 4.0 * tok * nh);
                 KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st, share0 && l == 0 ? B : 0));
             }
         } else {
@@ -1226,7 +1226,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             {   // dQ kernel: reads QKV, O and dO (row dots), writes dQ; dK/dV kernel: reads QKV and dO, writes dK | dV
                 const double tok = (double)RB * S, qtok = (shared ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
                 hipEvent_t mid = nullptr;
-                if (e->prof_on && (prof_wanted(e, named_class(e, "attn_bwd_dq_kernel")) || prof_wanted(e, named_class(e, "attn_bwd_dkv_kernel")))) {
+                if (e->prof_on && (prof_wanted(e, named_class(e, flash_attn_kernel_name(1, S, E, nh))) || prof_wanted(e, named_class(e, flash_attn_kernel_name(2, S, E, nh))))) {
                     if (e->prof_next + 1 > e->prof_pool.size())
                         for (int i = 0; i < 4096; ++i) {
                             hipEvent_t ev;
@@ -1235,8 +1235,8 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                         }
                     mid = e->prof_pool[e->prof_next++];
                 }
-                ProfScope ps(c, "attn_bwd_dkv_kernel", 8.0 * tok * S * E, es * (3.0 * qtok * E + tok * E + 2.0 * tok * E) + 8.0 * tok * nh);
-                ProfScope pq(c, "attn_bwd_dq_kernel", 6.0 * tok * S * E, es * (3.0 * qtok * E + 2.0 * tok * E + tok * E) + 8.0 * tok * nh);
+                ProfScope ps(c, flash_attn_kernel_name(2, S, E, nh), 8.0 * tok * S * E, es * (3.0 * qtok * E + tok * E + 2.0 * tok * E) + 8.0 * tok * nh);
+                ProfScope pq(c, flash_attn_kernel_name(1, S, E, nh), 6.0 * tok * S * E, es * (3.0 * qtok * E + 2.0 * tok * E + tok * E) + 8.0 * tok * nh);
                 KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0, mid));
                 if (mid) {          // both scopes opened before the pair: dq = [pq.e0, mid], dkv = [mid, ps.e1]
                     if (pq.on) { pq.r.e1 = mid; e->prof_recs.push_back(pq.r); pq.on = false; }

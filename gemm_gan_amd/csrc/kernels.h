@@ -135,6 +135,7 @@ void gp_time_next(hipEvent_t begin, hipEvent_t end);     // the next k_gp_* laun
 
 // fused self-attention (attention.hip): bf16 MFMA, no [S,S] tensor in HBM -----------------------------------
 bool flash_attn_supported(int S, int E, int nh);
+const char* flash_attn_kernel_name(int which, int S, int E, int nh);      // 0 forward, 1 dQ, 2 dK/dV: the kernel this shape runs on
 // qkv [N,S,3E] packed projections; mask [mask_B,S] bytes (row n % mask_B); ctx [N,S,E]; lse2 [N,nh,S].
 // io_bf16: qkv / ctx / dctx / dqkv are bf16 tensors (they only ever feed bf16 MFMA operands), else fp32.
 // qkv_B > 0: qkv holds the projection of the first qkv_B samples only and sample n reads sample n % qkv_B (dropout
