@@ -58,10 +58,10 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int ld, int col0, i
 }
 
 // global -> registers -> LDS staging of one [CT tokens x W features] chunk (W = 256), 4 x 16-byte pieces / thread
-template <bool BF, int W>
+template <bool BF, int W, int NT = 256>
 struct Stager {
     static constexpr int PPR = W / (BF ? 8 : 4);             // 16-byte pieces per row
-    static constexpr int NP = CT * PPR / 256;                // pieces per thread
+    static constexpr int NP = CT * PPR / NT;                 // pieces per thread
     u32x4 r[NP];
     f32x4 fga, fba, fgb, fbb;      // FiLM (fp32 X only): gamma / beta of the two samples a 32-token chunk can touch, this thread's columns
     int fsplit;                    // first row of the chunk that belongs to the second sample
@@ -75,7 +75,7 @@ struct Stager {
             const __bf16* p = reinterpret_cast<const __bf16*>(base);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {                        // piece = 8 bf16
-                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
                 long t = min(tok0 + row, tok_end - 1);
                 if (mod > 0) t %= mod;
                 const int cc = min(8 * pc, cols_valid - 8);
@@ -86,7 +86,7 @@ struct Stager {
             const float* p = reinterpret_cast<const float*>(base);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {                        // piece = 4 fp32
-                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
                 long t = min(tok0 + row, tok_end - 1);
                 if (mod > 0) t %= mod;
                 const int cc = min(4 * pc, cols_valid - 4);
@@ -107,7 +107,7 @@ struct Stager {
         zmask = 0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+            const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
             const int cc = min(EPP * pc, cols_valid - EPP);
             voff[i] = (unsigned)((row * ld + col0 + cc) * ES);
             if (EPP * pc >= cols_valid) zmask |= 1u << i;
@@ -133,7 +133,7 @@ struct Stager {
     __device__ __forceinline__ void store_film(__bf16* img, int ld, int tid) const {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+            const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
             const bool second = row >= fsplit;
             const f32x4 v = (second ? fgb : fga) * __builtin_bit_cast(f32x4, r[i]) + (second ? fbb : fba);
             u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
@@ -144,13 +144,13 @@ struct Stager {
         if constexpr (BF) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
                 *reinterpret_cast<u32x4*>(img + row * ld + 8 * pc) = ((zmask >> i) & 1u) ? u32x4{0u, 0u, 0u, 0u} : r[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int f = tid + 256 * i, row = f / PPR, pc = f % PPR;
+                const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
                 const f32x4 v = ((zmask >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, r[i]);
                 u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
                 *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
@@ -163,8 +163,10 @@ struct Stager {
 // weight matrix W [N,K] it belongs to:   dgamma[b,k] += sum_n W[n,k] C_b[n,k],   dbeta[b,k] += sum_n W[n,k] s_b[n],
 // s_b[n] = sum_tokens dY_b[token,n]  - the gradients of a FiLM modulation X' = gamma_b * X + beta_b that sits in front of
 // the Linear W, without materialising d(X') = dY W  (dgamma = sum_tokens dX' * X, dbeta = sum_tokens dX').
-template <bool YB, bool XB, bool FILM, bool FGRAD, bool FAST>
-__global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
+// W8: eight waves per workgroup (two per SIMD) on the same 128 x 256 panel - wave (wn, wk) owns 32 rows x 128 columns (4 accumulator
+// tiles, half the staging registers per thread): while one wave of a SIMD waits for its LDS fragments the other multiplies.
+template <bool YB, bool XB, bool FILM, bool FGRAD, bool FAST, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
                                                     float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
                                                     WgradFilmGrad fg, float* __restrict__ dbias, long x_mod) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
@@ -197,9 +199,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
     // 16-token step: every wave reads the WHOLE X chunk from LDS).  2 x 2 (T22): wave (wn, wk) owns 64 rows x 128 columns
     // (2 A + 4 B fragments): a third fewer LDS fragment reads for the same 8 MFMAs - the LDS read stream is what bounds the
     // kernel once its loads are prefetched.  The FiLM-gradient epilogue is written for the 4 x 1 map.
-    constexpr bool T22 = GG_WG_T22 && !FGRAD && WT == 1;
-    constexpr int TA = T22 ? 2 : WT, TB = T22 ? 4 : 8;
-    const int nb = T22 ? (wave >> 1) * 64 : wave * (32 * WT), kb = T22 ? (wave & 1) * 128 : 0;
+    static_assert(!W8 || (!FGRAD && WT == 1), "eight-wave tiling: plain weight gradient only");
+    constexpr int NT = W8 ? 512 : 256;
+    constexpr bool T22 = GG_WG_T22 && !FGRAD && WT == 1 && !W8;
+    constexpr int TA = T22 ? 2 : WT, TB = (T22 || W8) ? 4 : 8;
+    const int nb = W8 ? (wave & 3) * 32 : T22 ? (wave >> 1) * 64 : wave * (32 * WT), kb = W8 ? (wave >> 2) * 128 : T22 ? (wave & 1) * 128 : 0;
     float ssum2 = 0.f;                                  // T22: column sums of the wave's second 32-row tile
     f32x16 acc[TA][TB];
 #pragma unroll
@@ -220,9 +224,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
 #endif
     // ring depth by register budget (the branch-free loader keeps every stage live): a stage is 40 registers with bf16 dY,
     // 48 with fp32 dY, 64 with FiLM operands on top
-    constexpr int DEPTH = !FAST ? GG_WG_DEPTH : FILM ? GG_WG_DEPTH_FILM : !YB ? GG_WG_DEPTH_F32Y : GG_WG_DEPTH;
-    Stager<YB, PN> sy[DEPTH];
-    Stager<XB, PK> sx[DEPTH];
+#ifndef GG_WG_DEPTH_W8
+#define GG_WG_DEPTH_W8 2
+#endif
+    constexpr int DEPTH = !FAST ? GG_WG_DEPTH : W8 ? GG_WG_DEPTH_W8 : FILM ? GG_WG_DEPTH_FILM : !YB ? GG_WG_DEPTH_F32Y : GG_WG_DEPTH;
+    Stager<YB, PN, NT> sy[DEPTH];
+    Stager<XB, PK, NT> sx[DEPTH];
     const long nch = c_end - c_beg;
 #ifndef GG_WG_ABL
 #define GG_WG_ABL 0          // tools/wgrad_probe.hip ablations: 1 = no fragment reads / MFMAs, 2 = no LDS writes of X, 4 = no atomic
@@ -255,16 +262,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
         // whole chunks only (the host checks M % CT == 0 and x_mod % CT == 0): branch-free issue, see Stager::load_fast.
         // Issues past the last chunk repeat it (their data is written to LDS but never multiplied), so the loop body has
         // no conditional around a load and the compiler's wait counts are those of the steady state.
-        unsigned voy[Stager<YB, PN>::NP], vox[Stager<XB, PK>::NP], zmy, zmx;
-        Stager<YB, PN>::offsets(voy, zmy, ldy, n0, nvalid, tid);
-        Stager<XB, PK>::offsets(vox, zmx, ldx, k0, kvalid, tid);
-        const long ystep = (long)CT * ldy * Stager<YB, PN>::ES;
+        unsigned voy[Stager<YB, PN, NT>::NP], vox[Stager<XB, PK, NT>::NP], zmy, zmx;
+        Stager<YB, PN, NT>::offsets(voy, zmy, ldy, n0, nvalid, tid);
+        Stager<XB, PK, NT>::offsets(vox, zmx, ldx, k0, kvalid, tid);
+        const long ystep = (long)CT * ldy * Stager<YB, PN, NT>::ES;
         const char* ycur = reinterpret_cast<const char*>(dY) + c_beg * ystep;
         long xr = x_mod > 0 ? (c_beg * CT) % x_mod : c_beg * CT;          // row of X the next issue starts at
         long issued = 0;
-        auto issue = [&](Stager<YB, PN>& ys, Stager<XB, PK>& xs) {
+        auto issue = [&](Stager<YB, PN, NT>& ys, Stager<XB, PK, NT>& xs) {
             ys.load_fast(ycur, voy);
-            xs.load_fast(reinterpret_cast<const char*>(X) + xr * ldx * Stager<XB, PK>::ES, vox);
+            xs.load_fast(reinterpret_cast<const char*>(X) + xr * ldx * Stager<XB, PK, NT>::ES, vox);
             if constexpr (FILM) xs.load_film(film.g, film.b, film.ld, film.group, (c_beg + min(issued, nch - 1)) * CT, M, k0, kvalid, tid);
             if (issued + 1 < nch) {
                 ycur += ystep;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
             sy[st].store(Ysb(buf), LDY, tid, zmy);
             if constexpr (GG_WG_ABL & 2) {
                 u32x4 t = sx[st].r[0];
-                for (int i = 1; i < Stager<XB, PK>::NP; ++i) t |= sx[st].r[i];
+                for (int i = 1; i < Stager<XB, PK, NT>::NP; ++i) t |= sx[st].r[i];
                 if (t[0] == 0x12345678u) sx[st].store(Xsb(buf), LDX, tid);
             } else if constexpr (FILM) sx[st].store_film(Xsb(buf), LDX, tid);
             else sx[st].store(Xsb(buf), LDX, tid);
@@ -374,9 +381,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const void* __restrict__ dY,
                 if (h == 0 && nb + c < nvalid) atomicAdd(dbias + n0 + nb + c, ssum);
                 if (h == 0 && nb + 32 + c < nvalid) atomicAdd(dbias + n0 + nb + 32 + c, ssum2);
             }
-        } else {
+        } else if (!W8 || (wave >> 2) == 0) {                // W8: both column halves hold the same dY rows
             ssum += __shfl_xor(ssum, 32, 64);
-            if (h == 0 && wave * 32 + c < nvalid) atomicAdd(dbias + n0 + wave * 32 + c, ssum);
+            if (h == 0 && nb + c < nvalid) atomicAdd(dbias + n0 + nb + c, ssum);
         }
     }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
@@ -429,21 +436,23 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     // whole chunks and (for replica-shared inputs) a period of whole chunks: the branch-free loader; anything else (a ragged
     // last chunk) the general one
     static const bool no_fast = getenv("GG_WGRAD_GENERAL") != nullptr;
+    static const bool w8 = getenv("GG_WGRAD_W4") == nullptr;            // eight-wave tiling unless GG_WGRAD_W4 is set
     const bool fast = !no_fast && M % CT == 0 && (x_mod == 0 || x_mod % CT == 0) && ldy * 4 * CT < (1L << 31) / 1 && ldx * 4 * CT < (1L << 31);
-#define GG_WG1(YB, XB, FL, FG, FA)                                                                                         \
+#define GG_WG1(YB, XB, FL, FG, FA, W8_)                                                                                       \
     do {                                                                                                               \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL, FG, FA>),         \
+            GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<YB, XB, FL, FG, FA, W8_>),    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));                        \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG, FA>), grid, dim3(256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
+        hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG, FA, W8_>), grid, dim3(W8_ ? 512 : 256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
     } while (0)
 #define GG_WG(YB, XB, FL, FG)                  \
     do {                                       \
-        if (fast) GG_WG1(YB, XB, FL, FG, true); \
-        else GG_WG1(YB, XB, FL, FG, false);    \
+        if (fast && w8 && !FG) GG_WG1(YB, XB, FL, false, true, true); \
+        else if (fast) GG_WG1(YB, XB, FL, FG, true, false); \
+        else GG_WG1(YB, XB, FL, FG, false, false);    \
     } while (0)
     if (fgrad.W) {
         GG_WG(false, false, false, true);
