@@ -199,7 +199,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
     // 16-token step: every wave reads the WHOLE X chunk from LDS).  2 x 2 (T22): wave (wn, wk) owns 64 rows x 128 columns
     // (2 A + 4 B fragments): a third fewer LDS fragment reads for the same 8 MFMAs - the LDS read stream is what bounds the
     // kernel once its loads are prefetched.  The FiLM-gradient epilogue is written for the 4 x 1 map.
-    static_assert(!W8 || (!FGRAD && WT == 1), "eight-wave tiling: plain weight gradient only");
+    static_assert(!W8 || WT == 1, "eight-wave tiling: one 32-row tile per wave");
     constexpr int NT = W8 ? 512 : 256;
     constexpr bool T22 = GG_WG_T22 && !FGRAD && WT == 1 && !W8;
     constexpr int TA = T22 ? 2 : WT, TB = (T22 || W8) ? 4 : 8;
@@ -350,15 +350,15 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
         f32x4 sv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(&sl[8 * g + 4 * h]);
-        const float* wb = fg.W + (long)(n0 + wave * 32 + 4 * h) * fg.ldw + k0 + c;
+        const float* wb = fg.W + (long)(n0 + nb + 4 * h) * fg.ldw + k0 + kb + c;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < TB; ++b) {
             float vg = 0.f, vb = 0.f;
-            const bool colok = b * 32 + c < kvalid;
+            const bool colok = kb + b * 32 + c < kvalid;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2);
-                const bool ok = colok && wave * 32 + 4 * h + rr < nvalid;
+                const bool ok = colok && nb + 4 * h + rr < nvalid;
                 const float w = ok ? wb[(long)rr * fg.ldw + b * 32] : 0.f;
                 vg += acc[0][b][i] * w;
                 vb += sv[i >> 2][i & 3] * w;
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
             vg += __shfl_xor(vg, 32, 64);
             vb += __shfl_xor(vb, 32, 64);
             if (h == 0 && colok) {
-                atomicAdd(fg.dgamma + (long)split * fg.ld + k0 + b * 32 + c, vg);
-                atomicAdd(fg.dbeta + (long)split * fg.ld + k0 + b * 32 + c, vb);
+                atomicAdd(fg.dgamma + (long)split * fg.ld + k0 + kb + b * 32 + c, vg);
+                atomicAdd(fg.dbeta + (long)split * fg.ld + k0 + kb + b * 32 + c, vb);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -450,7 +450,7 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     } while (0)
 #define GG_WG(YB, XB, FL, FG)                  \
     do {                                       \
-        if (fast && w8 && !FG) GG_WG1(YB, XB, FL, false, true, true); \
+        if (fast && w8) GG_WG1(YB, XB, FL, FG, true, true); \
         else if (fast) GG_WG1(YB, XB, FL, FG, true, false); \
         else GG_WG1(YB, XB, FL, FG, false, false);    \
     } while (0)
