@@ -39,7 +39,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 #define GG_WG_T22 0
 #endif
 constexpr int WT = GG_WG_WT;                     // 32-row accumulator tiles per wave along n
-constexpr int PN = 128 * WT, PK = 256, CT = 32;  // panel rows / cols, tokens per chunk
+#ifndef GG_WG_CT
+#define GG_WG_CT 32
+#endif
+constexpr int PN = 128 * WT, PK = 256, CT = GG_WG_CT;  // panel rows / cols, tokens per chunk
 constexpr int LDY = PN + 32, LDX = PK + 32;      // bf16 per LDS row: 144 dwords (16 mod 64) -> conflict-free transpose reads
 
 // A / B fragment of the 16-token step s2 for the 32 features starting at col0: element j of lane (c, h) is
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
 #endif
     auto multiply = [&](int buf) {
 #pragma unroll
-        for (int s2 = 0; s2 < ((GG_WG_ABL & 1) ? 0 : 2); ++s2) {
+        for (int s2 = 0; s2 < ((GG_WG_ABL & 1) ? 0 : CT / 16); ++s2) {
             bf16x8 af[TA];
 #pragma unroll
             for (int a = 0; a < TA; ++a) af[a] = frag_tr(Ysb(buf), LDY, nb + a * 32, s2, lane);
