@@ -51,6 +51,19 @@ CASES = {
     # S = 257 = eight full 32-row tiles + the CLS row: the left-over query tile is shared by the four waves of a workgroup
     "cls_tail_S257": dict(cfg=PathConfig(n_genes=200, latent_dims=64, embedding_dims=256, hidden_dims=128, text_dims=64,
                                           patch_dims=64, dropout=0.0), B=3, P=256, T=1),
+    # edge shapes of the row-major attention kernels (attention.hip, *_rm): S a multiple of 32 (no clamped tile, no zero row),
+    # dh = 32; S a multiple of 8 but not of 32 (the zero row is an EXTRA row); S = 129 / 130 / 258: the left-over tile of one /
+    # two rows shared by the waves (dQ, dK/dV at four waves: 5 and 9 tiles; forward at eight waves: 9 tiles only), dh = 16
+    "tiles_S64_dh32": dict(cfg=PathConfig(n_genes=60, latent_dims=16, embedding_dims=128, hidden_dims=32, text_dims=24,
+                                           patch_dims=40, dropout=0.0), B=3, P=63, T=1),
+    "rows8_S40": dict(cfg=PathConfig(n_genes=60, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=24,
+                                      patch_dims=40, dropout=0.0), B=3, P=39, T=1),
+    "coop_S129": dict(cfg=PathConfig(n_genes=60, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=24,
+                                      patch_dims=40, dropout=0.0), B=2, P=128, T=1),
+    "coop2_S130_dh16": dict(cfg=PathConfig(n_genes=60, latent_dims=16, embedding_dims=64, hidden_dims=32, text_dims=24,
+                                            patch_dims=40, dropout=0.0), B=2, P=129, T=1),
+    "coop2_S258": dict(cfg=PathConfig(n_genes=60, latent_dims=16, embedding_dims=256, hidden_dims=32, text_dims=24,
+                                       patch_dims=40, dropout=0.0), B=2, P=257, T=1),
 }
 
 
@@ -305,7 +318,7 @@ def test_bf16_mode_tracks_fp32_oracle(flash):
 
 
 @pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged", "cls_tail_S257", "long_S601", "long_S545_E256", "long_S2047",
-                                  "img_long_S577_E256"])
+                                  "img_long_S577_E256", "tiles_S64_dh32", "rows8_S40", "coop_S129", "coop2_S130_dh16", "coop2_S258"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_flash_attention_matches_unfused_path(case, dropout):
     """Fused attention forward/backward (attention.hip) against the unfused bf16 path (GEMM + softmax +
