@@ -390,7 +390,15 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
         }
     }
     // ---- dW[n0 + ..][k0 + ..] += panel : C/D map col = lane&31 (k), row = (i&3) + 8*(i>>2) + 4*h (n)
+#ifdef GG_WG_L2ATOM
+    // probe (tools/wgrad_probe.hip only): per-XCD partial panels with L2-scope atomics - dW must hold 8 x N x ldw floats
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;                 // HW_REG_XCC_ID[3:0]
+    float* wbase = dW + (long)xcc * N * ldw + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
+#define GG_WG_PANEL_ADD(ptr, v) __hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
     float* wbase = dW + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
+#define GG_WG_PANEL_ADD(ptr, v) atomicAdd(ptr, v)
+#endif
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int rr = a * 32 + (i & 3) + 8 * (i >> 2);       // row inside the wave's slice (minus 4h)
-                    if (nb + 4 * h + rr < nvalid && !((GG_WG_ABL & 4) && acc[a][b][i] != 12345.f)) atomicAdd(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
+                    if (nb + 4 * h + rr < nvalid && !((GG_WG_ABL & 4) && acc[a][b][i] != 12345.f)) GG_WG_PANEL_ADD(wbase + (long)rr * ldw + b * 32, acc[a][b][i]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one tile's accumulators at a time: no mass copy-out (spills)
