@@ -395,6 +395,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
     const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;                 // HW_REG_XCC_ID[3:0]
     float* wbase = dW + (long)xcc * N * ldw + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
 #define GG_WG_PANEL_ADD(ptr, v) __hip_atomic_fetch_add(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#elif defined(GG_WG_STORE)
+    // probe (tools/wgrad_probe.hip only): plain stores of the partial panel into slice `split` of dW (splits x N x ldw floats), to be
+    // summed by a second pass
+    float* wbase = dW + (long)split * N * ldw + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
+#define GG_WG_PANEL_ADD(ptr, v) (*(ptr) = (v))
 #else
     float* wbase = dW + (long)(n0 + nb + 4 * h) * ldw + k0 + kb + c;
 #define GG_WG_PANEL_ADD(ptr, v) atomicAdd(ptr, v)
