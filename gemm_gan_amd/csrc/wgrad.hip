@@ -32,8 +32,11 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 #ifndef GG_WG_DEPTH
 #define GG_WG_DEPTH 4
 #endif
+// workgroups per launch (panels x token splits).  192, not one per CU: the kernel runs on side streams beside the main chain, and
+// leaving a quarter of the CUs to the main chain's kernels is worth more than the 8 % the launch itself loses (interleaved A/B,
+// ms per step: 160 -> 29.07, 192 -> 28.77, 208 -> 28.75, 224 -> 28.96, 256 -> 29.06)
 #ifndef GG_WG_TARGET
-#define GG_WG_TARGET 256
+#define GG_WG_TARGET 192
 #endif
 #ifndef GG_WG_T22
 #define GG_WG_T22 0
