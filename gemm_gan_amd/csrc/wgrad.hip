@@ -32,11 +32,12 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 #ifndef GG_WG_DEPTH
 #define GG_WG_DEPTH 4
 #endif
-// workgroups per launch (panels x token splits).  192, not one per CU: the kernel runs on side streams beside the main chain, and
-// leaving a quarter of the CUs to the main chain's kernels is worth more than the 8 % the launch itself loses (interleaved A/B,
-// ms per step: 160 -> 29.07, 192 -> 28.77, 208 -> 28.75, 224 -> 28.96, 256 -> 29.06)
+// workgroups per launch (panels x token splits): one per CU.  Fewer (a share of the CUs left to the main chain, the kernel runs on
+// side streams) measured 0.3 ms per step faster while the persistent Linears held ALL CUs (192 / 208: 28.75 against 29.06 ms);
+// since those leave 9 % of the CUs free themselves (wst.hip) the difference is within the A/B noise (192: 28.44, 224: 28.42,
+// 256: 28.56 ms) and the launch alone is 8 % slower at 192.
 #ifndef GG_WG_TARGET
-#define GG_WG_TARGET 192
+#define GG_WG_TARGET 256
 #endif
 #ifndef GG_WG_T22
 #define GG_WG_T22 0
