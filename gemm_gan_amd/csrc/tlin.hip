@@ -827,16 +827,32 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
     }
 }
 
-// one workgroup column per 2-D parameter: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows]
+// one workgroup column per 2-D parameter: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows].  32 x 32 tiles through LDS so
+// that both images are written in full 64-byte rows (the element-wise version wrote the transposed image one bf16 at a stride
+// of `rows`: 36 us per call, after every optimiser step and in front of the next forward pass).
 __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, __bf16* __restrict__ wtb,
                               const ShadowEntry* __restrict__ tab) {
+    __shared__ float t[32][33];
     const ShadowEntry e = tab[blockIdx.y];
-    const long n = (long)e.rows * e.cols;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / e.cols), c = (int)(i % e.cols);
-        const __bf16 v = (__bf16)w[e.off + i];
-        wb[e.off + i] = v;
-        wtb[e.off + (long)c * e.rows + r] = v;
+    const int tiles_c = (e.cols + 31) / 32, ntile = ((e.rows + 31) / 32) * tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 256 threads: 8 tile rows per pass
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            const bool in = r < e.rows && c < e.cols;
+            const float v = in ? w[e.off + (long)r * e.cols + c] : 0.f;
+            t[ty + 8 * k][tx] = v;
+            if (in) wb[e.off + (long)r * e.cols + c] = (__bf16)v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < e.rows && c < e.cols) wtb[e.off + (long)c * e.rows + r] = (__bf16)t[tx][ty + 8 * k];
+        }
+        __syncthreads();
     }
 }
 
