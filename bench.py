@@ -105,6 +105,46 @@ def pmc_traffic(cls):
     return round(b / n) if n else None
 
 
+def algorithmic_step(variant, B, G, P, T, Dt, Dp=1024, E=256, H=256, Lz=256, F=512, n_critic=5):
+    """algorithmic FLOPs and HBM bytes of ONE train() step (exact reference semantics, the reference's
+    zero-valued backward skipped, backward = 2 x forward); fp32 element sizes for the bytes, every raw tensor once per pass."""
+    S = P + 1
+    film = Dt * 2 * Dp if variant in ("xattn_film", "film") else 0
+    xattn = variant == "xattn_film"
+    enc = 2 * (S * E * 3 * E + 2 * S * S * E + S * E * E + 2 * S * E * F)
+    cond = film + (T * Dt * E if xattn else 0) + P * Dp * E + enc
+    if xattn:
+        cond += (2 * E * E + 2 * S * E * E + 2 * S * E) + (2 * E * E + 2 * T * E * E + 2 * T * E)
+    if variant == "vanilla":
+        cond = 0
+    mlp_d = (G + E) * H + H * H + H
+    mlp_g = (Lz + E) * H + H * H + H * G
+    mac = n_critic * ((cond + mlp_g) + 3 * (cond + mlp_d) + 4 * (cond + mlp_d) + 3 * mlp_d) + \
+        ((cond + mlp_g) + (cond + mlp_d) + mlp_d + 2 * (cond + mlp_g))
+    flops = 2.0 * mac * B
+    gp = n_critic * (5.0 * G * 4 * B + 3.0 * H * G * 4)                       # GP chain: x, x~, x^, grad (w + r) + W1x per GEMM
+    passes = 0 if variant == "vanilla" else 6 * n_critic + 3                  # conditioning passes that touch the raw patches
+    patch = passes * P * Dp * 4.0 * B
+    return flops, gp + patch, {"gp_chain_bytes": gp, "patch_stream_bytes": patch}
+
+
+def pmc_step_bytes(args):
+    """HBM bytes of one step through the PMC counters, from the committed summary of this round (tools/pmc_traffic.sh on this
+    same command); None when the summary is of another workload."""
+    for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+        except Exception:
+            continue
+        if not (args.variant == "xattn_film" and args.batch == 256 and args.genes == 5000 and args.patches == 256 and
+                args.tokens == 1 and args.precision == "bf16" and args.pad_frac == 0):
+            return None, None
+        steps = d.get("steps_profiled", 2)                                    # bench.py --steps 1 --warmup 1
+        tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in d["kernels"].values())
+        return tot / steps, f
+    return None, None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -386,6 +426,27 @@ def main():
                                "kernel_classes": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 2),
                                                      "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                                                      "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in (rows_all or rows)]}
+        # whole-step roofline: algorithmic work against the step's wall time, and the HBM bytes the step really moves
+        fl, by, parts = algorithmic_step(args.variant, B, G, P, T, args.text_dims)
+        peak_tf_step = PEAK_TFLOPS["f32" if args.precision == "f32" else "bf16"]    # fp8 mode: most of the step's MFMAs are bf16
+        pmc_b, pmc_f = pmc_step_bytes(args)
+        step = {"algorithmic_flops": fl, "algorithmic_hbm_bytes": by, **parts,
+                "achieved_TFLOP/s": round(fl / (ms * 1e-3) / 1e12, 1), "peak_TFLOP/s": peak_tf_step,
+                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / peak_tf_step, 4),
+                "ideal_ms_mfma": round(fl / (peak_tf_step * 1e12) * 1e3, 3), "ideal_ms_hbm": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 3),
+                "pmc_hbm_bytes": pmc_b, "pmc_source": pmc_f,
+                "pmc_over_algorithmic": round(pmc_b / by, 2) if pmc_b else None,
+                "frac_hbm_on_pmc_bytes": round(pmc_b / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pmc_b else None,
+                "note": "algorithmic = SURVEY.md 8(d) formulas (FLOPs = 2 x MACs of the reference's necessary work; bytes = gradient-"
+                        "penalty chain + raw patch stream in fp32); pmc = sum over the heavy kernels of launches x (2*FETCH_SIZE + "
+                        "WRITE_SIZE)*1024 from the committed rocprofv3 passes of this command, per step"}
+        if "roofline" in out:
+            out["roofline"]["step"] = step
+        else:
+            out["roofline_step"] = step
+        if world > 1:
+            out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                           "buckets_per_optimizer_step": 2, "optimizer_steps_per_train": 6}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

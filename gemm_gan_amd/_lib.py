@@ -100,6 +100,8 @@ SYMBOLS = {
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
                                     C.c_int, C.c_void_p]),
     "gg_launch_count": (C.c_int64, [C.c_void_p]),
+    "gg_reset_launch_count": (C.c_int, [C.c_void_p]),
+    "gg_bind_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gg_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "gg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_profile_enable_class": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -175,6 +175,7 @@ struct gg_engine {
     int bstore_on = 1;         // store MFMA-operand-only tensors in bf16 (bf16 mode, flash + tlin paths)
     // weight gradients are leaves of the backward chain: they run on a second stream beside the data-gradient kernels
     hipStream_t side = nullptr;
+    bool side_own = true, pre_own = true;      // false: the stream was bound by the host (gg_bind_streams) and outlives the engine
     hipEvent_t ev_ready = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool side_pending[4] = {false, false, false, false};
     int side_on = 1;
@@ -977,8 +978,8 @@ bool side_begin(Ctx& c, Ctx& cs) {
     static const bool env_off = getenv("GG_NO_SIDE_WGRAD") != nullptr;
     cs = c;
     if (!e->side_on || env_off) return false;
-    if (!e->side) {
-        if (!create_side_stream(&e->side)) return false;
+    if (!e->ev_ready) {
+        if (!e->side && !create_side_stream(&e->side)) return false;
         bool ok = hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { e->side_on = 0; return false; }
@@ -1625,11 +1626,11 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in, boo
     // a critic conditioning pass computed ahead lives in the critic's arena: the generator passes take the spare one, in order
     const bool spare = e->dcond_valid;
     if (spare) pipe = false;
-    if (pipe && !e->pre_stream) {
-        bool ok = create_side_stream(&e->pre_stream);
+    if (pipe && !e->pre_fork) {
+        bool ok = e->pre_stream != nullptr || create_side_stream(&e->pre_stream);
         ok = ok && hipEventCreateWithFlags(&e->pre_fork, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < GG_MAX_PREFETCH; ++k) ok = ok && hipEventCreateWithFlags(&e->pre_ev[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { e->pre_stream = nullptr; pipe = false; }
+        if (!ok) { e->pre_fork = nullptr; pipe = false; }
     }
     if (!pipe) {
         for (int done = 0; done < n;) {
@@ -1789,18 +1790,18 @@ void gg_destroy(gg_engine* e) {
     if (!e) return;
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    if (e->pre_stream) {
-        (void)hipStreamSynchronize(e->pre_stream);
+    if (e->pre_stream) (void)hipStreamSynchronize(e->pre_stream);
+    if (e->pre_fork) {
         (void)hipEventDestroy(e->pre_fork);
-        for (int k = 0; k < GG_MAX_PREFETCH; ++k) (void)hipEventDestroy(e->pre_ev[k]);
-        (void)hipStreamDestroy(e->pre_stream);
+        for (int k = 0; k < GG_MAX_PREFETCH; ++k) if (e->pre_ev[k]) (void)hipEventDestroy(e->pre_ev[k]);
     }
-    if (e->side) {
-        (void)hipStreamSynchronize(e->side);
+    if (e->pre_stream && e->pre_own) (void)hipStreamDestroy(e->pre_stream);
+    if (e->side) (void)hipStreamSynchronize(e->side);
+    if (e->ev_ready) {
         (void)hipEventDestroy(e->ev_ready);
-        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e->ev_done[i]);
-        (void)hipStreamDestroy(e->side);
+        for (int i = 0; i < 4; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     }
+    if (e->side && e->side_own) (void)hipStreamDestroy(e->side);
     delete e;
 }
 
@@ -2200,6 +2201,19 @@ int gg_set_optimizer_step(gg_engine* e, int role, int step) {
     return 0;
 }
 int64_t gg_launch_count(const gg_engine* e) { return e ? e->launches : -1; }
+int gg_reset_launch_count(gg_engine* e) {
+    GG_REQUIRE(e, "null argument");
+    e->launches = 0;
+    return 0;
+}
+// Host-owned streams for the engine's concurrent work (see gemmgan.h).  Must precede the first call that forks onto them.
+int gg_bind_streams(gg_engine* e, void* side, void* prefetch) {
+    GG_REQUIRE(e && side && prefetch && side != prefetch, "two distinct streams expected");
+    GG_REQUIRE(!e->ev_ready && !e->pre_fork, "gg_bind_streams must be called before the engine's first iteration");
+    e->side = (hipStream_t)side; e->side_own = false;
+    e->pre_stream = (hipStream_t)prefetch; e->pre_own = false;
+    return 0;
+}
 
 int gg_profile_enable(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");

@@ -7,6 +7,7 @@ gradient all-reduce.  All arithmetic of the hot path happens in libgemmgan.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -52,8 +53,14 @@ class Engine:
             self._alloc_workspace()
             self.losses = torch.zeros(L.N_LOSSES, dtype=torch.float32, device=self.device)
             self.graph, self._stage, self._zeros = False, {}, {}
+            # The engine's concurrent work (parameter-gradient leaves, generator passes computed ahead) runs on two streams
+            # this object owns and binds: kernels on them read the caller's input tensors after an entry point has returned,
+            # and the caching allocator orders a block's reuse only against streams the tensor was recorded on (_borrow).
+            prio = -1 if os.environ.get("GG_SIDE_PRIO", "") .startswith("h") else 0
+            self._side_stream = torch.cuda.Stream(self.device, priority=prio)
+            self._pre_stream = torch.cuda.Stream(self.device, priority=prio)
+            L.check(self.lib.gg_bind_streams(self.h, C.c_void_p(self._side_stream.cuda_stream), C.c_void_p(self._pre_stream.cuda_stream)))
         self.dropout = float(dropout)
-        self._keep_ring = []
         off, numel = C.c_int64(), C.c_int64()
         self.mlp_range = {}
         for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
@@ -118,13 +125,18 @@ class Engine:
             raise ValueError("padding mask shape mismatch")
         pp, tp = self._mask_bytes(patch_pad), self._mask_bytes(text_pad)
         keep = (patches, pp, text, tp)
-        # The engine's own streams (generator prefetch, side leaves) may still read these buffers after the C call returns;
-        # the caching allocator orders frees against the CURRENT stream only, so the last few argument sets stay referenced
-        # here until later calls (each of which joins the engine's streams) have been enqueued.
-        self._keep_ring.append(keep)
-        if len(self._keep_ring) > 16:
-            self._keep_ring.pop(0)
+        self._borrow(*keep)
         return L.GGCond(patches.data_ptr(), pp.data_ptr(), text.data_ptr(), tp.data_ptr(), B, P, T), keep
+
+    def _borrow(self, *tensors):
+        """Inputs are borrowed for the call, but kernels on the engine's side / prefetch streams may read them after it has
+        returned (and after the caller dropped its reference).  Recording the tensor on those streams makes the caching
+        allocator hold the block until the work enqueued on them so far has finished - an ordering guarantee, where
+        earlier rounds kept the last 16 argument sets alive and hoped."""
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(self._side_stream)
+                t.record_stream(self._pre_stream)
 
     def _mask_bytes(self, m: torch.Tensor) -> torch.Tensor:
         """torch.bool masks are one byte per element: the kernels read the caller's tensor in place (no uint8 temporary)."""
@@ -149,13 +161,14 @@ class Engine:
     def critic_backward(self, x_real, z, alpha, patches, patch_pad, text, text_pad):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         alpha = alpha.reshape(-1).contiguous()
+        self._borrow(x_real, z, alpha)
         L.check(self.lib.gg_critic_backward(self.h, _ptr(x_real), _ptr(z), _ptr(alpha), C.byref(cond), _ptr(self.losses), _stream()))
 
     def critic_backward_head(self, x_real, z, alpha, patches, patch_pad, text, text_pad):
         """First phase of a critic iteration: returns with the MLP-head gradient slots (`mlp_range`) complete."""
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         alpha = alpha.reshape(-1).contiguous()
-        self._keep_ring.append((x_real, z, alpha))
+        self._borrow(x_real, z, alpha)
         L.check(self.lib.gg_critic_backward_head(self.h, _ptr(x_real), _ptr(z), _ptr(alpha), C.byref(cond), _ptr(self.losses), _stream()))
 
     def critic_backward_cond(self, patches, patch_pad, text, text_pad):
@@ -180,12 +193,12 @@ class Engine:
             raise ValueError("alpha must have one entry per sample")
         out = torch.zeros(1, dtype=torch.float32, device=self.device)
         L.check(self.lib.gg_gradient_penalty(self.h, _ptr(x_real), _ptr(x_fake), _ptr(alpha), C.byref(cond), int(train), _ptr(out), _stream()))
-        self._keep_ring.append((x_real, x_fake, alpha))
+        self._borrow(x_real, x_fake, alpha)
         return out[0]
 
     def generator_backward_head(self, z, patches, patch_pad, text, text_pad):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
-        self._keep_ring.append((z,))
+        self._borrow(z)
         L.check(self.lib.gg_generator_backward_head(self.h, _ptr(z), C.byref(cond), _ptr(self.losses), _stream()))
 
     def generator_backward_cond(self, patches, patch_pad, text, text_pad):
@@ -197,6 +210,7 @@ class Engine:
 
     def generator_backward(self, z, patches, patch_pad, text, text_pad):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        self._borrow(z)
         L.check(self.lib.gg_generator_backward(self.h, _ptr(z), C.byref(cond), _ptr(self.losses), _stream()))
 
     def generator_apply(self, grad_scale=1.0):
@@ -207,6 +221,7 @@ class Engine:
         generator is frozen in between); the following critic_backward calls consume them in order."""
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         assert z_all.dim() == 3 and z_all.is_contiguous()
+        self._borrow(z_all)
         L.check(self.lib.gg_generator_prefetch(self.h, _ptr(z_all), int(z_all.shape[0]), C.byref(cond), _stream()))
 
     def set_side_streams(self, on):
@@ -251,6 +266,7 @@ class Engine:
         assert z_all.shape[0] == n_critic + 1 and z_all.is_contiguous() and alpha_all.is_contiguous()
         if getattr(self, "graph", False):
             z_all, alpha_all = self._staged("z", z_all), self._staged("alpha", alpha_all)
+        self._borrow(x_real, z_all, alpha_all)
         L.check(self.lib.gg_train_step(self.h, _ptr(x_real), C.byref(cond), _ptr(z_all), _ptr(alpha_all), n_critic,
                                        _ptr(self.losses), _stream()))
 
@@ -343,3 +359,6 @@ class Engine:
 
     def launch_count(self):
         return int(self.lib.gg_launch_count(self.h))
+
+    def reset_launch_count(self):
+        L.check(self.lib.gg_reset_launch_count(self.h))

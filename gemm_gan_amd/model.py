@@ -503,6 +503,7 @@ class WGAN_GP:
         else:
             # One flat-buffer SUM all-reduce per optimiser step, issued as two buckets so that it overlaps the backward
             # (SURVEY 8e); clip + step on the averaged gradient, identical on every rank.
+            eng.reset_launch_count()                                                    # gg_train_step does this by itself
             if n > 1:
                 eng.generator_prefetch(z_all[:n].contiguous(), pat, ppad, text, tpad)   # frozen generator: all n passes at once
             for k in range(n):

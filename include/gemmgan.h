@@ -238,8 +238,16 @@ int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* 
 /* gradient-penalty kernels (csrc/gpchain.hip) on the buffers of the last critic iteration with batch B: us[4] / bytes[4] = average
  * microseconds (the dispatches' own timestamps) and algorithmic HBM bytes per launch of gp_front_k, gp_grad_k, gp_coef_k, gp_tail_k */
 int gg_gp_profile(gg_engine* e, int B, int reps, double* us, double* bytes, void* stream);
-/* counters of the last gg_train_step / iteration: kernels launched */
+/* kernels launched since the start of the last gg_train_step, or since gg_reset_launch_count (hosts that drive the step
+ * through the two-phase entries - the data-parallel loop - reset it themselves at the top of their train()) */
 int64_t gg_launch_count(const gg_engine* e);
+int gg_reset_launch_count(gg_engine* e);
+/* Streams for the engine's concurrent work, owned by the host: `side` carries the parameter-gradient leaves and the frozen
+ * critic's forward of the generator iteration, `prefetch` the generator passes computed ahead (R:463-477 allows both: see
+ * gg_set_side_streams / gg_generator_prefetch).  Without this call the engine creates its own.  Binding them lets the host
+ * framework order the lifetime of borrowed input tensors against them (torch: Tensor.record_stream) - kernels on these
+ * streams read the caller's conditioning inputs after an entry point has returned.  Call before the first iteration. */
+int gg_bind_streams(gg_engine* e, void* side, void* prefetch);
 
 /* ---- evaluation: nearest reference records ---------------------------------------------
  * The device-side math of the reference's privacy metrics DCR / NNDR (src/privacy_evaluator.py:9-66): for every query row

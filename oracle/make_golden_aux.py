@@ -15,6 +15,9 @@ Fixtures
   aux_prdc.npz           src/distribution_distances.py:102-142  compute_prdc (L1 distances) for three k
   aux_knn_pr.npz         src/unsupervised_metrics.py:141-303  ManifoldEstimator / knn_precision_recall_features /
                          get_precision_recall (squared Euclidean distances, <= radius)
+  aux_privacy.npz        src/privacy_evaluator.py:9-66  dcr / nndr run by the reference itself (its `.cuda()` calls made
+                         no-ops for the duration of the call: the container has no GPU; the arithmetic is the same torch
+                         expressions on the CPU), scores plus the per-sample distance / ratio vectors it concatenates
 """
 from __future__ import annotations
 
@@ -164,9 +167,49 @@ def knn_pr():
     print("wrote", path)
 
 
+def privacy():
+    """dcr / nndr of src/privacy_evaluator.py:9-66 on small sets that exercise what the metric exists for (exact and near
+    copies of training records), the reference's batching (fewer than, exactly, and more than one batch of 128 generated rows)
+    (no exact ties: a strict comparison at a tie is fp32 rounding in any implementation).  torch.Tensor.cuda is an identity while the reference runs; torch.cat is wrapped to keep the per-sample vectors."""
+    ref = import_reference("privacy_evaluator")
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = {"small": (40, 90, 33, 17), "one_batch": (128, 60, 70, 24), "multi_batch": (300, 150, 120, 64)}
+    out["cases"] = np.array(sorted(cases))
+    for name, (nq, nr, nt, dim) in cases.items():
+        real = rng.standard_normal((nr, dim)).astype(np.float32)
+        test = rng.standard_normal((nt, dim)).astype(np.float32)
+        gen = rng.standard_normal((nq, dim)).astype(np.float32)
+        gen[0] = real[3]                                                          # exact copy of a training record
+        gen[2] = real[0] + 1e-3 * rng.standard_normal(dim).astype(np.float32)     # near copy
+        gen[5] = test[1]                                                          # exact copy of a test record
+        cat_rec = []
+        orig_cuda, orig_cat = torch.Tensor.cuda, torch.cat
+
+        def cat(xs, *a, **k):
+            o = orig_cat(xs, *a, **k)
+            cat_rec.append(o.detach().clone().numpy())
+            return o
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.cat = cat
+        try:
+            s_dcr = ref.dcr(real, gen, test)
+            s_nndr = ref.nndr(real, gen, test)
+        finally:
+            torch.Tensor.cuda, torch.cat = orig_cuda, orig_cat
+        assert len(cat_rec) == 4
+        out[f"{name}/real"], out[f"{name}/test"], out[f"{name}/gen"] = real, test, gen
+        out[f"{name}/scores"] = np.array([s_dcr, s_nndr], dtype=np.float64)
+        out[f"{name}/dcr_real"], out[f"{name}/dcr_test"] = cat_rec[0], cat_rec[1]
+        out[f"{name}/nndr_real"], out[f"{name}/nndr_test"] = cat_rec[2], cat_rec[3]
+    path = os.path.join(OUT_DIR, "aux_privacy.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {n: out[f"{n}/scores"].tolist() for n in cases})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     only = set(sys.argv[1:])
-    for fn in (loader_items, loader_split, prdc, knn_pr):
+    for fn in (loader_items, loader_split, prdc, knn_pr, privacy):
         if not only or fn.__name__ in only:
             fn()

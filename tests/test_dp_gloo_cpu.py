@@ -84,6 +84,9 @@ class OracleEngine:
     def critic_apply(self, scale):
         self._apply(L.ROLE_CRITIC, scale, self.tr.cfg.clip_d, self.tr.opt_d)
 
+    def reset_launch_count(self):
+        self.resets = getattr(self, "resets", 0) + 1
+
     def generator_prefetch(self, z_all, pat, ppad, text, tpad):
         pass        # a scheduling hint of the HIP engine (batched generator passes): same results without it
 

@@ -20,13 +20,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("fixture", ["xattn_film_T3"])
 def test_two_ranks_on_one_gpu_equal_one_rank_on_the_global_batch(fixture, tmp_path):
+    _two_ranks(fixture, tmp_path, "gloo")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (`nccl`) backend, one rank per device")
+@pytest.mark.parametrize("fixture", ["xattn_film_T3"])
+def test_two_ranks_on_two_gpus_over_rccl_equal_one_rank_on_the_global_batch(fixture, tmp_path):
+    """The same assertion over the backend bench.py's N > 1 runs use: RCCL, rank r on GPU r, asynchronous bucket all-reduces on
+    RCCL's own stream.  torch.cuda.device_count() above does not initialise the GPU; the children are started before the parent
+    touches it and nothing replaces a running process."""
+    _two_ranks(fixture, tmp_path, "nccl")
+
+
+def _two_ranks(fixture, tmp_path, backend):
     sys.path.insert(0, HERE)
     import dp_worker
     world = 2
-    port = str(29600 + os.getpid() % 1500)
+    port = str(29600 + os.getpid() % 1500 + (7 if backend == "nccl" else 0))
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, fixture, outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, fixture, outs[r], backend],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:
@@ -67,3 +81,8 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_global_batch(fixture, tmp_pa
     assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7)                            # reported losses are global means
     assert np.allclose(l0, np.array(ref_losses), rtol=5e-3, atol=5e-4), (l0, ref_losses)
     assert float(got[0]["comm_wait_ms"]) >= 0.0
+    assert str(got[0]["backend"]) == backend and int(got[0]["world"]) == world
+    # kernel launches of the LAST train() only (the data-parallel loop resets the counter itself): the same on both ranks and
+    # of the size of one step, not the running total of two
+    la, lb = got[0]["launches"], got[1]["launches"]
+    assert np.array_equal(la, lb) and la[0] > 0 and la[1] <= la[0], (la, lb)     # (step 2 consumes a conditioning pass step 1 ran ahead)

@@ -105,3 +105,25 @@ def test_knn_precision_recall_equals_the_recorded_reference_values():
         assert (p, r) == pytest.approx(tuple(z[f"k{k}/precision_recall"]), abs=1e-12)
         st = evaluate.knn_precision_recall_features(z["real"], z["fake"], nhood_sizes=[k])
         assert st["precision"].shape == (1,) and st["recall"].shape == (1,)
+
+
+@pytest.mark.parametrize("case", ["small", "one_batch", "multi_batch"])
+def test_dcr_nndr_equal_the_recorded_reference_values(case):
+    """src/privacy_evaluator.py:9-66 dcr / nndr run by the reference itself (oracle/make_golden_aux.py::privacy; its `.cuda()`
+    calls were no-ops in the GPU-less build container): the scores, and the per-sample nearest / second-nearest distances
+    behind them, against the HIP nearest-record kernel."""
+    z = np.load(os.path.join(GOLDEN, "aux_privacy.npz"))
+    real, test, gen = (z[f"{case}/{k}"] for k in ("real", "test", "gen"))
+    want_dcr, want_nndr = z[f"{case}/scores"]
+    r1, r2 = evaluate.nearest2(torch.from_numpy(gen).cuda(), torch.from_numpy(real).cuda())
+    t1, t2 = evaluate.nearest2(torch.from_numpy(gen).cuda(), torch.from_numpy(test).cuda())
+    assert np.allclose(r1.cpu().numpy(), z[f"{case}/dcr_real"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(t1.cpu().numpy(), z[f"{case}/dcr_test"], rtol=1e-5, atol=1e-6)
+    # ratios: 0 / d2 for the exact copies on both sides; elsewhere fp32 rounding of two square roots
+    assert np.allclose((r1 / r2).cpu().numpy(), z[f"{case}/nndr_real"], rtol=2e-5, atol=1e-6)
+    assert np.allclose((t1 / t2).cpu().numpy(), z[f"{case}/nndr_test"], rtol=2e-5, atol=1e-6)
+    # the scores are counts of strict comparisons; no pair of this fixture sits within fp32 rounding of a tie
+    margin = np.abs(z[f"{case}/dcr_real"] - z[f"{case}/dcr_test"]).min()
+    assert margin > 1e-4
+    assert evaluate.dcr(real, gen, test) == pytest.approx(float(want_dcr), abs=1e-12)
+    assert evaluate.nndr(real, gen, test) == pytest.approx(float(want_nndr), abs=1e-12)
