@@ -31,6 +31,22 @@ class GGConfig(C.Structure):
                 ("seed", C.c_uint64), ("precision", C.c_int32), ("variant", C.c_int32)]
 
 
+class GGTestLinear(C.Structure):       # gg_test_linear_args (include/gemmgan.h)
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int64), ("x_bf16", C.c_int32),
+                ("W", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+                ("Y", C.c_void_p), ("ldy", C.c_int64), ("y_bf16", C.c_int32), ("y_rows", C.c_int64),
+                ("N", C.c_int32), ("K", C.c_int32),
+                ("film_g", C.c_void_p), ("film_b", C.c_void_p), ("film_ld", C.c_int64), ("film_group", C.c_int32),
+                ("y_row_group", C.c_int32), ("act_relu", C.c_int32),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_site", C.c_uint32), ("drop_call", C.c_uint32),
+                ("drop_ld", C.c_int64),
+                ("mask_ref", C.c_void_p), ("ldref", C.c_int64), ("mask_scale", C.c_float), ("mask_bf16", C.c_int32),
+                ("accumulate", C.c_int32),
+                ("res", C.c_void_p), ("ldres", C.c_int64), ("res_rows", C.c_int64),
+                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p),
+                ("route", C.c_int32)]
+
+
 class GGCond(C.Structure):
     _fields_ = [("patches", C.c_void_p), ("patch_pad", C.c_void_p), ("text", C.c_void_p),
                 ("text_pad", C.c_void_p), ("B", C.c_int32), ("P", C.c_int32), ("T", C.c_int32)]
@@ -99,6 +115,22 @@ SYMBOLS = {
     "gg_test_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float,
                                     C.c_int, C.c_void_p]),
+    "gg_test_linear": (C.c_int, [C.POINTER(GGTestLinear), C.POINTER(C.c_int32), C.c_void_p]),
+    "gg_test_attn_kernel_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gg_test_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.c_void_p]),
+    "gg_test_attn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_int64, C.c_void_p]),
+    "gg_test_wgrad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gg_test_sqx_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
+    "gg_test_sqx_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gg_test_ln_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "gg_launch_count": (C.c_int64, [C.c_void_p]),
     "gg_reset_launch_count": (C.c_int, [C.c_void_p]),
     "gg_bind_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

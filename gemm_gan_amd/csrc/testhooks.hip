@@ -1,0 +1,105 @@
+// Kernel-level test entry points (tests/ only; declared in include/gemmgan.h under "test hooks").
+//
+// Each hook launches ONE kernel family of the hot path exactly as engine.hip does - same host wrappers, same routing
+// (weight-stationary -> token-on-lane Linear, resident -> streaming attention) - on buffers the test supplies, so that
+// tests/test_kernels_gpu.py can compare the kernels the bench times against a float64 product of host-rounded
+// operands, dropout included (the mask is regenerated on the host from the (seed, site, call) triple: drop_rng.h).
+#include "../../include/gemmgan.h"
+#include "gg_common.h"
+#include "kernels.h"
+
+using namespace gg;
+
+namespace gg {
+void tlin_force_route(int route);        // tlin.hip: 0 = as in production, 1 = never the weight-stationary kernels
+int tlin3(const TlinP& p, hipStream_t st);
+bool tlin3_supported(const TlinP& p);
+}
+
+extern "C" {
+
+int gg_test_linear(const gg_test_linear_args* a, int32_t* kernel_class, void* stream) {
+    GG_REQUIRE(a && a->X && a->W && a->Y, "null argument");
+    TlinP p;
+    p.X = a->X; p.ldx = a->ldx; p.M = a->M; p.x_bf16 = a->x_bf16;
+    p.W = a->W; p.ldw = a->ldw; p.bias = a->bias;
+    p.Y = a->Y; p.ldy = a->ldy; p.y_bf16 = a->y_bf16; p.y_rows = a->y_rows;
+    p.N = a->N; p.K = a->K;
+    p.film_g = a->film_g; p.film_b = a->film_b; p.film_ld = a->film_ld; p.film_group = a->film_group;
+    p.y_row_group = a->y_row_group;
+    p.act_relu = a->act_relu;
+    p.drop = make_drop_key(a->drop_p, a->drop_seed, a->drop_site, a->drop_call); p.drop_ld = a->drop_ld;
+    p.mask_ref = a->mask_ref; p.ldref = a->ldref; p.mask_scale = a->mask_scale; p.mask_bf16 = a->mask_bf16;
+    p.accumulate = a->accumulate;
+    p.res = a->res; p.ldres = a->ldres; p.res_rows = a->res_rows > 0 ? a->res_rows : 1;
+    p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.ln_y = a->ln_y; p.ln_stats = a->ln_stats;
+    if (a->route == 2) {                // split-operand (bf16x3) Linear: fp32 X, fp32 W, fp32 Y
+        GG_REQUIRE(tlin3_supported(p), "gg_test_linear: no bf16x3 instantiation for this call");
+        if (kernel_class) *kernel_class = 64;
+        return tlin3(p, (hipStream_t)stream);
+    }
+    GG_REQUIRE(tlin_supported(p), "gg_test_linear: the Linear kernels do not take this shape / alignment");
+    tlin_force_route(a->route);
+    if (kernel_class) *kernel_class = tlin_kernel_class(p);
+    const int rc = tlin(p, (hipStream_t)stream);
+    tlin_force_route(0);
+    return rc;
+}
+
+const char* gg_test_attn_kernel_name(int which, int S, int E, int nh) { return flash_attn_kernel_name(which, S, E, nh); }
+
+int gg_test_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, int64_t N, int S, int E, int nh,
+                     float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_call, int io_bf16, int64_t qkv_B,
+                     void* stream) {
+    GG_REQUIRE(qkv && ctx && lse2, "null argument");
+    GG_REQUIRE(flash_attn_supported(S, E, nh), "gg_test_attn_fwd: unsupported shape");
+    return flash_attn_fwd(qkv, mask, mask_B, ctx, lse2, N, S, E, nh, make_drop_key(drop_p, drop_seed, drop_site, drop_call), io_bf16,
+                          (hipStream_t)stream, qkv_B);
+}
+
+int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                     int mask_B, void* dqkv, int64_t N, int S, int E, int nh, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                     uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream) {
+    GG_REQUIRE(qkv && ctx && dctx && lse2 && delta && dqkv, "null argument");
+    GG_REQUIRE(flash_attn_supported(S, E, nh), "gg_test_attn_bwd: unsupported shape");
+    return flash_attn_bwd(qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, N, S, E, nh,
+                          make_drop_key(drop_p, drop_seed, drop_site, drop_call), io_bf16, (hipStream_t)stream, qkv_B, nullptr);
+}
+
+int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
+                  int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
+                  int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,
+                  void* stream) {
+    GG_REQUIRE(dY && X, "null argument");
+    GG_REQUIRE(wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K), "gg_test_wgrad: the token-reduction kernel does not take this shape");
+    WgradFilm film;
+    film.g = film_g; film.b = film_b; film.ld = film_ld; film.group = film_group;
+    WgradFilmGrad fg;
+    fg.W = fgrad_W; fg.ldw = fgrad_ldw; fg.dgamma = dgamma; fg.dbeta = dbeta; fg.ld = fgrad_ld; fg.tokens = fgrad_tokens;
+    return wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, (hipStream_t)stream, film_g ? &film : nullptr,
+                 fgrad_W ? &fg : nullptr, dbias, x_mod);
+}
+
+int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int mask_B, float* probs, float* xbar, int N, int S, int E,
+                    int nh, void* stream) {
+    GG_REQUIRE(qt && x && probs && xbar, "null argument");
+    GG_REQUIRE(sqx_stream_supported(S, E, nh), "gg_test_sqx_fwd: unsupported shape");
+    return sqx_stream_fwd(qt, x, mask, mask_B, probs, xbar, N, S, E, nh, (hipStream_t)stream);
+}
+
+int gg_test_sqx_bwd(const float* dxbar, const float* qt, const float* xbar, const float* x, const float* probs, float* dx, float* dqt,
+                    int N, int S, int E, int nh, void* stream) {
+    GG_REQUIRE(dxbar && qt && xbar && x && probs && dx && dqt, "null argument");
+    GG_REQUIRE(sqx_stream_supported(S, E, nh), "gg_test_sqx_bwd: unsupported shape");
+    return sqx_stream_bwd(dxbar, qt, xbar, x, probs, dx, dqt, N, S, E, nh, (hipStream_t)stream);
+}
+
+int gg_test_ln_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out, float* dgamma,
+                   float* dbeta, float* dbias, int64_t rows, int E, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                   uint32_t drop_call, int dres_bf16, void* stream) {
+    GG_REQUIRE(dy && r && stats && g && dr && dgamma && dbeta, "null argument");
+    return k_layernorm_bwd(dy, r, stats, g, dr, dres_out, dgamma, dbeta, dbias, rows, E,
+                           make_drop_key(drop_p, drop_seed, drop_site, drop_call), (hipStream_t)stream, dres_bf16);
+}
+
+}  // extern "C"

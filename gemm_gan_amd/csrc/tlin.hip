@@ -990,7 +990,10 @@ bool tlin_supported(const TlinP& p) {
 
 // which kernel tlin() launches for p (profiling classes follow the kernels' own names): 0 tlin_str_kernel, 1 tlin_res_kernel
 // (32-token waves), 2 tlin_res16_kernel<..., PRE_RES> (+ residual + LayerNorm), 3 <..., PRE_ACC> (+=), 4 other res16 modes
+static int g_route = 0;                   // tests (gg_test_linear): 1 = keep the token-on-lane kernels
+void tlin_force_route(int route) { g_route = route; }
 bool wst_routed(const TlinP& p) {
+    if (g_route == 1) return false;
     static const bool off = getenv("GG_NO_WST") != nullptr;
     static const bool off2 = getenv("GG_NO_WST2") != nullptr;
     if (off || p.fp8) return false;
@@ -1077,5 +1080,9 @@ int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// split-operand (bf16x3) Linear: filled in by the bf16x3 mode
+bool tlin3_supported(const TlinP&) { return false; }
+int tlin3(const TlinP&, hipStream_t) { set_error("tlin3: not built"); return -2; }
 
 }  // namespace gg

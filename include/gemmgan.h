@@ -218,6 +218,49 @@ int gg_test_gemm_bf16_stored(const void* A, const void* B, float* C, int M, int 
 int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
                       int64_t ldc, int layA, int layB, int splitk, float alpha, const float* bias, int act,
                       float slope, int accumulate, void* stream);
+/* ---- kernel-level hooks (csrc/testhooks.hip): ONE kernel family of the hot path on buffers the test supplies, launched
+ * through the same host wrappers and routing as the engine; tests/test_kernels_gpu.py compares them with float64 products of
+ * host-rounded operands.  Dropout keys are made from (p, seed, site, call) exactly as the engine makes them (csrc/drop_rng.h). */
+typedef struct gg_test_linear_args {     /* Y = epi(X W^T): the encoder-layer Linears (torch transformer.py:940-983 via R:213) */
+    const void* X; int64_t ldx; int64_t M; int32_t x_bf16;       /* activations [M,K], fp32 or bf16 (ld in elements)          */
+    const void* W; int64_t ldw;                                  /* [N,K]: bf16 (routes 0, 1) or fp32 (route 2)                */
+    const float* bias;
+    void* Y; int64_t ldy; int32_t y_bf16; int64_t y_rows;        /* y_rows: with LayerNorm, rows whose pre-LN sum is stored   */
+    int32_t N, K;
+    const float* film_g; const float* film_b; int64_t film_ld; int32_t film_group;   /* X' = g[m / group] * X + b[m / group] */
+    int32_t y_row_group;                                         /* output row m -> m + m / group + 1 (CLS row per sample)     */
+    int32_t act_relu;
+    float drop_p; uint64_t drop_seed; uint32_t drop_site, drop_call; int64_t drop_ld;   /* element index = row * drop_ld + n  */
+    const void* mask_ref; int64_t ldref; float mask_scale; int32_t mask_bf16;           /* y = ref > 0 ? y * scale : 0        */
+    int32_t accumulate;                                          /* y += previous content                                      */
+    const float* res; int64_t ldres; int64_t res_rows;           /* + res[row % res_rows]                                      */
+    const float* ln_g; const float* ln_b; float* ln_y; float* ln_stats;                  /* LayerNorm of the sum (eps 1e-5)    */
+    int32_t route;     /* 0: as the engine routes it (weight-stationary kernel when one takes the shape), 1: token-on-lane kernels only,
+                          2: the split-operand (bf16x3) Linear of GG_PREC_BF16X3                                                    */
+} gg_test_linear_args;
+int gg_test_linear(const gg_test_linear_args* a, int32_t* kernel_class, void* stream);
+/* fused self-attention (torch functional.py:6206-6660): qkv [qkv_B or N, S, 3E] packed, mask [mask_B, S] bytes, ctx [N, S, E],
+ * lse2 [N, nh, S] (log2-sum-exp of the scaled scores); backward: dctx -> dqkv [N, S, 3E], delta [N, nh, S] scratch */
+const char* gg_test_attn_kernel_name(int which, int S, int E, int nh);     /* 0 forward, 1 dQ, 2 dK|dV */
+int gg_test_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, int64_t N, int S, int E, int nh,
+                     float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream);
+int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                     int mask_B, void* dqkv, int64_t N, int S, int E, int nh, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                     uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream);
+/* dW [N,K] += dY [M,N]^T X [M,K] over the token rows (+ optional FiLM on X, FiLM-gradient contraction, bias column sums) */
+int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
+                  int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
+                  int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,
+                  void* stream);
+/* projection-free single-query attention sweeps (R:218-219 restated): qt [N,nh,E], x [N,S,E] -> probs [N,nh,S], xbar [N,nh,E] */
+int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int mask_B, float* probs, float* xbar, int N, int S, int E,
+                    int nh, void* stream);
+int gg_test_sqx_bwd(const float* dxbar, const float* qt, const float* xbar, const float* x, const float* probs, float* dx, float* dqt,
+                    int N, int S, int E, int nh, void* stream);
+/* LayerNorm backward with the dropout-masked branch gradient (fp32 or bf16) and the fused bias / gamma / beta column sums */
+int gg_test_ln_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out, float* dgamma,
+                   float* dbeta, float* dbias, int64_t rows, int E, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                   uint32_t drop_call, int dres_bf16, void* stream);
 /* device pointer + element count of a named internal activation buffer of the LAST call, e.g.
  * "D.x0", "D.L0.P", "G.c", "X2", "gp_grad" (list in engine.hip); lets tests localise a mismatch. */
 int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel);
