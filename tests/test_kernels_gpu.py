@@ -7,7 +7,11 @@ the host from the (seed, site, call) triple with a numpy restatement of csrc/dro
 in fp32 and the one rounding of a bf16-stored output, hence the bounds
 
     fp32 outputs   rel-L2 <= 1e-4   (measured 1e-7 .. 1e-6)
-    bf16 outputs   rel-L2 <= 2e-3   (one bf16 rounding: 2^-9 / sqrt(3) = 1.1e-3 rms) and max-norm <= 2^-8
+    bf16 outputs   rel-L2 <= 2e-3   (one bf16 rounding, unit roundoff 2^-8: 1.6 - 1.7e-3 rms measured) and max-norm <= 2^-8
+    attention      rel-L2 <= 3.2e-3 (bf16 storage) / 2.5e-3 (fp32 storage): besides the stored result the kernels round ONE
+                   intermediate tile to bf16 - the probabilities (forward, dV) or dS (dQ, dK), the B operand of the second
+                   product - relative to a reference exponent only the kernel knows (lazy online-softmax maximum), so the host
+                   cannot reproduce that rounding bit for bit; two independent roundings give 2.3e-3 rms (measured 1.8 - 2.5e-3)
 
 - one to two orders tighter than the mode-level gates of tests/test_bf16_parity_gpu.py (whose gradient bounds carry the
 ReLU-gate flips of a whole network).  A wrong fragment map, tile tail, mask, dropout index or epilogue gives O(1) here.
@@ -75,15 +79,14 @@ def rel_max(got, want):
     return float((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
 
 
-def check(name, got, want, bf16_out):
+def check(name, got, want, bf16_out, l2_bound=None, max_bound=None):
     got = got.detach().cpu()
     assert torch.isfinite(got.float()).all(), name
     l2, mx = rel_l2(got, want), rel_max(got, want)
     diag(f"   {name:44s} rel-L2 {l2:.2e}  max-norm {mx:.2e}  ({'bf16' if bf16_out else 'fp32'} output)")
-    if bf16_out:
-        assert l2 <= 2e-3 and mx <= 2.0 ** -8, (name, l2, mx)
-    else:
-        assert l2 <= 1e-4 and mx <= 2e-4, (name, l2, mx)
+    l2_bound = l2_bound or (2e-3 if bf16_out else 1e-4)
+    max_bound = max_bound or (2.0 ** -8 if bf16_out else 2e-4)
+    assert l2 <= l2_bound and mx <= max_bound, (name, l2, mx)
 
 
 def stream():
@@ -162,8 +165,9 @@ def ref_linear(*, X, W, N, K, bias=None, y_bf16=False, relu=False, drop=None, ma
     """float64 restatement of the epilogue chain of tlin.hip / wst.hip: bias -> ReLU -> dropout -> gate -> (+ previous) ->
     (+ residual) -> LayerNorm(eps 1e-5)."""
     M = X.shape[0]
-    Xe = X.double()
+    Xe = bf(X)                                                              # fp32 activations are converted to bf16 on load
     if film is not None:
+        Xe = X.float().double()
         g, b, group = film
         idx = torch.arange(M) // group
         Xe = bf((g.double()[idx] * Xe + b.double()[idx]).float())          # modulated in fp32, rounded to bf16 on the way to LDS
@@ -299,7 +303,7 @@ def attn_inputs(N, S, E, nh, seed, pad):
     return qkv, mask, dctx
 
 
-def ref_attention(qkv, mask, dctx, ctx_stored, nh, drop, lse_kernel=None):
+def ref_attention(qkv, mask, dctx, ctx_stored, nh, drop, dctx_stored=None):
     """float64 forward and backward on the values the kernels multiply (qkv / dctx already rounded as stored).  Backward follows the
     kernels' own formulas: delta = rowsum(dO * O_stored), P from the forward's log-sum-exp."""
     N, S, E3 = qkv.shape
@@ -330,7 +334,9 @@ def ref_attention(qkv, mask, dctx, ctx_stored, nh, drop, lse_kernel=None):
     if dctx is not None:
         do = dctx.reshape(N, S, nh, dh).permute(0, 2, 1, 3).double()
         ost = ctx_stored.reshape(N, S, nh, dh).permute(0, 2, 1, 3).double()
-        delta = (do * ost).sum(-1, keepdim=True)
+        # delta = rowsum(dO * O) is VALU arithmetic on the tensors as stored (fp32 storage: the un-rounded dO)
+        dst = do if dctx_stored is None else dctx_stored.reshape(N, S, nh, dh).permute(0, 2, 1, 3).double()
+        delta = (dst * ost).sum(-1, keepdim=True)
         dv = pd.transpose(-1, -2) @ do
         dp = (do @ v.transpose(-1, -2)) * keep * ks
         ds = p * (dp - delta) * sc
@@ -364,9 +370,10 @@ def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf
     dp = drop or (0.0, 0, 0, 0)
     names = [lib.gg_test_attn_kernel_name(w, S, E, nh).decode() for w in range(3)]
     diag(f"== attention S={S} dh={dh} io_bf16={io_bf16} pad={pad} dropout={drop_on}: {names}")
-    assert names[0] == ("attn_fwd_rm_kernel" if S < 1000 else "attn_fwd_stream_kernel")
-    assert names[1] == ("attn_bwd_dq_rm_kernel" if S < 1000 else "attn_bwd_dq_stream_kernel")
-    assert names[2] == ("attn_bwd_dkv_rm_kernel" if S < 1000 else "attn_bwd_dkv_stream_kernel")
+    if dh == 64:        # the production head width: the kernels the bench times (cfg3: *_rm, configs[4]: *_stream)
+        assert names[0] == ("attn_fwd_rm_kernel" if S < 1000 else "attn_fwd_stream_kernel")
+        assert names[1] == ("attn_bwd_dq_rm_kernel" if S < 1000 else "attn_bwd_dq_stream_kernel")
+        assert names[2] == ("attn_bwd_dkv_rm_kernel" if S < 1000 else "attn_bwd_dkv_stream_kernel")
     L.check(lib.gg_test_attn_fwd(P(qkv_d), P(mask_d), N, P(ctx_d), P(lse_d), N, S, E, nh, C.c_float(dp[0]), dp[1], dp[2], dp[3],
                                  io_bf16, 0, stream()))
     delta_d = torch.zeros(N, nh, S, device=DEV)
@@ -375,15 +382,16 @@ def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf
                                  C.c_float(dp[0]), dp[1], dp[2], dp[3], io_bf16, 0, stream()))
     torch.cuda.synchronize()
     # the kernels convert fp32 operands to bf16 on load: the reference multiplies those values in both storage modes
-    want = ref_attention(bf(qkv_d.cpu()), mask, bf(dctx_d.cpu()), ctx_d.cpu().double(), nh, drop)
-    check("context", ctx_d, want["ctx"], True)               # P is rounded to bf16 for the P V product in both modes
+    want = ref_attention(bf(qkv_d.cpu()), mask, bf(dctx_d.cpu()), ctx_d.cpu().double(), nh, drop, dctx_stored=dctx_d.cpu().double())
+    bl2, bmx = (3.2e-3, 2.0 ** -7) if io_bf16 else (2.5e-3, 2.0 ** -7)
+    check("context", ctx_d, want["ctx"], True, bl2, bmx)
     valid = ~mask[:, None, :].expand(N, nh, S)
     check("log2-sum-exp", lse_d.cpu(), want["lse2"], False)
     dq, dk, dv = (dqkv_d[:, :, i * E:(i + 1) * E] for i in range(3))
     wq, wk, wv = (want["dqkv"][:, :, i * E:(i + 1) * E] for i in range(3))
-    check("dQ", dq, wq, True)
-    check("dK", dk, wk, True)
-    check("dV", dv, wv, True)
+    check("dQ", dq, wq, True, bl2, bmx)
+    check("dK", dk, wk, True, bl2, bmx)
+    check("dV", dv, wv, True, bl2, bmx)
     # masked keys receive exactly zero gradient
     mk = mask[:, :, None].expand(N, S, E)
     assert float(dk.float().cpu()[mk].abs().max() if mk.any() else 0.0) == 0.0
@@ -412,8 +420,8 @@ def test_attention_replicas_share_the_layer0_projection():
     torch.cuda.synchronize()
     want = ref_attention(bf(qkv_d.cpu()).repeat(R, 1, 1), mask.repeat(R, 1), bf(dctx_d.cpu()), ctx_d.cpu().double(), nh, drop)
     diag("== attention with a replica-shared projection (qkv_B = 2, N = 6)")
-    check("context", ctx_d, want["ctx"], True)
-    check("dqkv", dqkv_d, want["dqkv"], True)
+    check("context", ctx_d, want["ctx"], True, 3.2e-3, 2.0 ** -7)
+    check("dqkv", dqkv_d, want["dqkv"], True, 3.2e-3, 2.0 ** -7)
     assert rel_l2(ctx_d[:B].cpu(), ctx_d[B:2 * B].cpu().double()) > 1e-2       # replicas draw their own dropout masks
 
 
@@ -549,5 +557,4 @@ def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
     check("masked branch gradient", dres_d, dres, bool(dres_bf16))
     check("dgamma", dg_d, (dy.double() * xh).sum(0), False)
     check("dbeta", db_d, dy.double().sum(0), False)
-    # the bias gradient sums what the next kernels consume: the stored (bf16-rounded) values when stored as bf16
-    check("fused bias gradient", dbias_d, (bf(dres.float()) if dres_bf16 else dres).sum(0), False)
+    check("fused bias gradient", dbias_d, dres.sum(0), False)        # column sums of the fp32 values, before the bf16 store
