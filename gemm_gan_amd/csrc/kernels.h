@@ -184,6 +184,11 @@ void tlin_time_next(hipEvent_t begin, hipEvent_t end);     // the next tlin() la
 // 0 stream (K != 256), 1 resident 32-token, 2/3/4 resident 16-token (+res+LN / += / other),
 // 16 + XB + 2*YB + 4*EPI: the tlin_str_kernel<256, XB, YB, EPI> instantiation
 int tlin_kernel_class(const TlinP& p);
+// split-operand (bf16x3) Linear of GG_PREC_BF16X3 (tlin3.hip): same TlinP contract with fp32 X, fp32 W (the master copy, [N][K]),
+// fp32 Y and fp32 gate reference; three bf16 MFMAs per product tile on hi / lo splits, fp32 accumulate
+bool tlin3_supported(const TlinP& p);
+int tlin3(const TlinP& p, hipStream_t st);
+void tlin3_time_next(hipEvent_t begin, hipEvent_t end);
 // bf16 shadow copies of the 2-D weights: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows], same offsets
 struct ShadowEntry { long off; int rows, cols; };
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);

@@ -12,8 +12,6 @@ using namespace gg;
 
 namespace gg {
 void tlin_force_route(int route);        // tlin.hip: 0 = as in production, 1 = never the weight-stationary kernels
-int tlin3(const TlinP& p, hipStream_t st);
-bool tlin3_supported(const TlinP& p);
 }
 
 extern "C" {

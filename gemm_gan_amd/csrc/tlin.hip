@@ -1081,8 +1081,4 @@ int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab
     return 0;
 }
 
-// split-operand (bf16x3) Linear: filled in by the bf16x3 mode
-bool tlin3_supported(const TlinP&) { return false; }
-int tlin3(const TlinP&, hipStream_t) { set_error("tlin3: not built"); return -2; }
-
 }  // namespace gg

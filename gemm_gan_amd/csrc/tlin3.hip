@@ -1,0 +1,339 @@
+// Split-operand ("bf16x3") token-on-lane Linear: the precision mode GG_PREC_BF16X3.
+//
+//   Y[M,N] = epi( X[M,K] W[N,K]^T ),   X, W, Y fp32 in memory
+//
+// Every fp32 operand value v is split on its way into LDS into  hi = bf16(v)  and  lo = bf16(v - hi)  (v = hi + lo up to
+// 2^-17 relative), and each product tile is three bf16 MFMAs accumulated in fp32:
+//
+//   X W^T  ~=  Xhi Whi^T + Xlo Whi^T + Xhi Wlo^T        (the dropped Xlo Wlo^T term is 2^-16 relative)
+//
+// i.e. fp32-grade products (measured 2e-6 .. 1e-5 relative against float64) at 3/16 of the bf16 MFMA rate instead of the 1/16
+// of the fp32-input MFMA - on the SAME kernel structure as tlin_res_kernel (tlin.hip): a wave owns 32 tokens whose activations
+// are register-resident MFMA B fragments, the weights stream through a double-buffered LDS chunk of 32 output features shared
+// by the four waves, accumulators have features in registers and tokens on lanes, so bias, ReLU, dropout (same counter-hash
+// stream, same element index), the ReLU gate of a backward product, +=, the residual add and LayerNorm are in-lane epilogue
+// code.  Differences: K slices of 128 (two fragment sets per slice), weights read as fp32 from the master copy (no shadow),
+// column groups of <= 256 features in grid.y for the wide products (QKV 3 x 256, FFN1 2 x 256), run-time epilogue flags.
+// The engine's 1e-3 parity tests (tests/test_engine_golden_gpu.py, tests/test_engine_oracle_gpu.py) run in this mode.
+#include "kernels.h"
+#include "drop_rng.h"
+#include <hip/hip_ext.h>
+
+namespace gg {
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr float LN_EPS = 1e-5f;
+constexpr int KSL = 128, WLD = KSL + 8;
+
+// v -> (hi, lo) pairs of two values, packed as bf16x2 words
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+    const bf16x2_t h = {ah, bh};
+    const bf16x2_t l = {(__bf16)(a - (float)ah), (__bf16)(b - (float)bh)};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+    unsigned h0, l0, h1, l1;
+    split2(v[0], v[1], h0, l0);
+    split2(v[2], v[3], h1, l1);
+    hi = u32x2{h0, h1};
+    lo = u32x2{l0, l1};
+}
+
+// rows [tok0, tok0 + 32) x [k0, k0 + KSL) of X (fp32, FiLM optional) as hi / lo bf16 images into the wave-private slabs
+__device__ __forceinline__ void stage_x3(const TlinP& p, __bf16* xh, __bf16* xl, int tok0, int last_tok, int k0, int lane) {
+    asm volatile("" : "+v"(tok0));
+    const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
+    constexpr int LPR = KSL / 4, RPI = 64 / LPR, NLD = 32 / RPI, GB = 8;      // 32 lanes per row, 2 rows per instruction, 16 loads
+    const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
+    const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, ba = {0.f, 0.f, 0.f, 0.f}, gb = ga, bb = ba;
+    int tb = 0, rem0 = 0;
+    if (p.film_g) {         // FiLM rows are per sample (film_group >= 32 tokens): a 32-token tile touches at most two of them
+        tb = min(tok0, last_tok);
+        const int g0 = tb / p.film_group;
+        rem0 = tb - g0 * p.film_group;
+        const int g1 = min(g0 + 1, last_tok / p.film_group);
+        const unsigned fldb = (unsigned)p.film_ld * 4u;
+        const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g) + cb;
+        const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b) + cb;
+        ga = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g0 * fldb); ba = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g0 * fldb);
+        gb = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g1 * fldb); bb = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g1 * fldb);
+    }
+    f32x4 v[2][GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) v[0][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
+#pragma unroll
+    for (int b0 = 0; b0 < NLD; b0 += GB) {
+        const int cur = (b0 / GB) & 1;
+        if (b0 + GB < NLD) {
+#pragma unroll
+            for (int i = 0; i < GB; ++i)
+                v[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + GB + i), last_tok) * ldb + cb));
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            f32x4 m = v[cur][i];
+            if (p.film_g) {
+                const int r = min(tok0 + lrow + RPI * (b0 + i), last_tok);
+                const bool second = rem0 + (r - tb) >= p.film_group;
+                m = (second ? gb : ga) * m + (second ? bb : ba);
+            }
+            u32x2 hi, lo;
+            split4(m, hi, lo);
+            const int o = (RPI * (b0 + i) + lrow) * WLD + lcol;
+            *reinterpret_cast<u32x2*>(&xh[o]) = hi;
+            *reinterpret_cast<u32x2*>(&xl[o]) = lo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT_RES>
+__global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
+    const DropKey dkey = drop_live(p.drop);
+    constexpr int N = 32 * NT_RES;                     // columns of this workgroup's group
+    constexpr int WLOADS = 32 * (KSL / 4) / 256;       // float4 pieces per thread and weight chunk (4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const Wh = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
+    __bf16* const Wl = Wh + 2 * 32 * WLD;                                   // [2][32*WLD]
+    __bf16* const Xh = Wl + 2 * 32 * WLD;                                   // [4][32*WLD]
+    __bf16* const Xl = Xh + 4 * 32 * WLD;                                   // [4][32*WLD]
+    float* const Ps = reinterpret_cast<float*>(Xl + 4 * 32 * WLD);          // bias | gamma | beta  [3][N]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int gcol = (int)blockIdx.y * N;
+    const int tok0 = (int)blockIdx.x * 128 + wave * 32;
+    const int last_tok = (int)p.M - 1;
+    const int nks = p.K / KSL;
+    const int nchunks = nks * NT_RES;
+    __bf16* const xh = Xh + wave * 32 * WLD;
+    __bf16* const xl = Xl + wave * 32 * WLD;
+
+    // weight chunks (32 output features x KSL, fp32) travel L2 -> registers -> (split) -> LDS two chunks ahead of their use
+    f32x4 wreg[2][WLOADS];
+    const float* Wp = reinterpret_cast<const float*>(p.W);
+    auto load_chunk = [&](int set, int ks, int nt) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (KSL / 4), piece = f % (KSL / 4);
+            wreg[set][i] = *reinterpret_cast<const f32x4*>(Wp + (long)(gcol + nt * 32 + row) * p.ldw + ks * KSL + 4 * piece);
+        }
+    };
+    auto store_chunk = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (KSL / 4), piece = f % (KSL / 4);
+            u32x2 hi, lo;
+            split4(wreg[set][i], hi, lo);
+            *reinterpret_cast<u32x2*>(&Wh[set * 32 * WLD + row * WLD + 4 * piece]) = hi;
+            *reinterpret_cast<u32x2*>(&Wl[set * 32 * WLD + row * WLD + 4 * piece]) = lo;
+        }
+    };
+
+    load_chunk(0, 0, 0);
+    load_chunk(1, 0, 1);
+    for (int i = tid; i < N; i += 256) {
+        Ps[i] = p.bias ? p.bias[gcol + i] : 0.f;
+        Ps[N + i] = p.ln_g ? p.ln_g[i] : 1.f;
+        Ps[2 * N + i] = p.ln_g ? p.ln_b[i] : 0.f;
+    }
+    store_chunk(0);
+
+    const int tok = tok0 + c;
+    const bool valid = tok <= last_tok;
+    const int tokc = valid ? tok : last_tok;           // clamped lanes recompute the last row; their stores are predicated off
+    const long yrow = p.y_row_group ? (long)tokc + tokc / p.y_row_group + 1 : (long)tokc;
+    float* const yb = reinterpret_cast<float*>(p.Y) + yrow * p.ldy + gcol;
+    const float* const resp = p.res ? p.res + (long)(tokc % (int)p.res_rows) * p.ldres + gcol : nullptr;
+    const float* const mref = p.mask_ref ? reinterpret_cast<const float*>(p.mask_ref) + (long)tokc * p.ldref + gcol : nullptr;
+    const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
+    const bool has_pre = resp != nullptr || p.accumulate != 0;
+
+    f32x16 acc[NT_RES];
+    bf16x8 xfh[KSL / 16], xfl[KSL / 16];
+    // epilogue operands (residual rows / previous output, gate reference) travel one feature tile ahead of their use: tile 0 is
+    // requested before the last MFMA pass, tile nt + 1 while tile nt is finished (all of them up front cost 128 registers: spills)
+    f32x4 pre[2][4], mrf[2][4];
+    auto load_pre = [&](int nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + 4 * h;
+            if (has_pre) {
+                pre[nt & 1][g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.accumulate) pre[nt & 1][g] += *reinterpret_cast<const f32x4*>(yb + n);
+            }
+            if (mref) mrf[nt & 1][g] = *reinterpret_cast<const f32x4*>(mref + n);
+        }
+    };
+
+    int chunk = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        stage_x3(p, xh, xl, tok0, last_tok, ks * KSL, lane);
+        if (ks == nks - 1) load_pre(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KSL / 16; ++s) {
+            xfh[s] = *reinterpret_cast<const bf16x8*>(&xh[c * WLD + 16 * s + 8 * h]);
+            xfl[s] = *reinterpret_cast<const bf16x8*>(&xl[c * WLD + 16 * s + 8 * h]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();     // chunk `chunk` is in W?[chunk & 1] (and Ps on the first pass)
+
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt) {
+            const int buf = nt & 1;      // compile-time after unrolling (NT_RES is even): chunk & 1 == nt & 1
+            if (chunk + 2 < nchunks) load_chunk(buf, nt + 2 >= NT_RES ? ks + 1 : ks, (nt + 2) % NT_RES);
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            }
+            const __bf16* whb = Wh + buf * 32 * WLD + c * WLD + 8 * h;
+            const __bf16* wlb = Wl + buf * 32 * WLD + c * WLD + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KSL / 16; ++s) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whb + 16 * s);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
+                // small terms first, the leading product last
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xfh[s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xfl[s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xfh[s], acc[nt], 0, 0, 0);
+            }
+            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+            ++chunk;
+        }
+    }
+
+    // ---- epilogue: bias -> ReLU -> dropout -> gate -> (+ previous / residual) -> store ; LayerNorm over the N features ----------
+    const bool drop_on = p.drop.p > 0.f;
+    const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
+    const uint64_t dbase = (uint64_t)tokc * p.drop_ld + gcol;
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT_RES; ++nt) {
+        if (nt + 1 < NT_RES) load_pre(nt + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + 4 * h;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[n]);
+            f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            v += bb;
+            if (p.act_relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (drop_on) {
+                float f[4];
+                drop_factor4(dkey, dbase + n, ksd, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= f[j];
+            }
+            if (mref) {
+                const f32x4 m = mrf[nt & 1][g];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] * p.mask_scale : 0.f;
+            }
+            if (has_pre) v += pre[nt & 1][g];
+            if (valid && keep_y) *reinterpret_cast<f32x4*>(yb + n) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[nt][4 * g + j] = v[j];
+                sum += v[j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.ln_g) {
+        const float invn = 1.f / (float)N;
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * invn;
+        float var = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float d = acc[nt][i] - mean;
+                var += d * d;
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * invn + LN_EPS);
+        float* const lb = p.ln_y + (long)tokc * p.ldy;
+#pragma unroll
+        for (int nt = 0; nt < NT_RES; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nt * 32 + 8 * g + 4 * h;
+                const f32x4 gg_ = *reinterpret_cast<const f32x4*>(&Ps[N + n]);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[2 * N + n]);
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (acc[nt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
+                if (valid) *reinterpret_cast<f32x4*>(lb + n) = y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (h == 0 && valid && keep_y) {
+            p.ln_stats[2 * (long)tok] = mean;
+            p.ln_stats[2 * (long)tok + 1] = rstd;
+        }
+    }
+}
+
+hipEvent_t g3_ev0 = nullptr, g3_ev1 = nullptr;
+
+template <int NT_RES>
+int launch3(const TlinP& p, int groups, hipStream_t st) {
+    constexpr size_t smem = (size_t)(2 * 2 + 2 * 4) * 32 * WLD * 2 + (size_t)3 * 32 * NT_RES * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin3_kernel<NT_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)groups);
+    if (g3_ev0) {
+        hipExtLaunchKernelGGL(tlin3_kernel<NT_RES>, grid, dim3(256), (unsigned)smem, st, g3_ev0, g3_ev1, 0, p);
+        g3_ev0 = g3_ev1 = nullptr;
+    } else {
+        hipLaunchKernelGGL(tlin3_kernel<NT_RES>, grid, dim3(256), smem, st, p);
+    }
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+}  // namespace
+
+void tlin3_time_next(hipEvent_t begin, hipEvent_t end) { g3_ev0 = begin; g3_ev1 = end; }
+
+// fp32 X / W / Y (and fp32 gate reference); N a multiple of 32 up to 256, or a multiple of 256 (column groups); K a multiple of 128
+bool tlin3_supported(const TlinP& p) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (double)p.M * (double)p.ldx * 4.0 >= 4.0e9) return false;      // 32-bit row offsets
+    if (p.x_bf16 || p.y_bf16 || p.fp8 || (p.mask_ref && p.mask_bf16)) return false;
+    if (p.K % KSL) return false;
+    if (!(p.N == 64 || p.N == 128 || p.N == 256 || (p.N > 256 && p.N % 256 == 0))) return false;
+    if (p.ln_g && (p.N > 256 || !p.ln_b || !p.ln_y || !p.ln_stats || !al16(p.ln_y))) return false;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % 4 || p.ldy % 4 || p.ldw % 4) return false;
+    if (p.film_g && (!al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group < 32)) return false;
+    if (p.mask_ref && (!al16(p.mask_ref) || p.ldref % 4)) return false;
+    if (p.res && (!al16(p.res) || p.ldres % 4 || p.res_rows < 1)) return false;
+    if (p.drop.p > 0.f && p.drop_ld % 2) return false;
+    return true;
+}
+
+int tlin3(const TlinP& p, hipStream_t st) {
+    GG_REQUIRE(tlin3_supported(p), "tlin3: unsupported shape / alignment");
+    if (p.N == 64) return launch3<2>(p, 1, st);
+    if (p.N == 128) return launch3<4>(p, 1, st);
+    return launch3<8>(p, p.N / 256, st);
+}
+
+}  // namespace gg

@@ -140,8 +140,8 @@ def run_linear(*, X, W, N, K, bias=None, y_bf16=False, x_bf16=False, relu=False,
         a.drop_p, a.drop_seed, a.drop_site, a.drop_call = drop
         a.drop_ld = N
     if mask_ref is not None:
-        mr = dev(mask_ref, torch.bfloat16)
-        a.mask_ref, a.ldref, a.mask_scale, a.mask_bf16 = mr.data_ptr(), N, mask_scale, 1
+        mr = dev(mask_ref, torch.float32 if route == 2 else torch.bfloat16)
+        a.mask_ref, a.ldref, a.mask_scale, a.mask_bf16 = mr.data_ptr(), N, mask_scale, int(route != 2)
     a.accumulate = int(accumulate is not None)
     if res is not None:
         rd = dev(res, torch.float32)
@@ -161,16 +161,17 @@ def run_linear(*, X, W, N, K, bias=None, y_bf16=False, x_bf16=False, relu=False,
 
 
 def ref_linear(*, X, W, N, K, bias=None, y_bf16=False, relu=False, drop=None, mask_ref=None, mask_scale=1.0, accumulate=None,
-               res=None, res_rows=0, ln=None, film=None, **_):
+               res=None, res_rows=0, ln=None, film=None, exact=False, **_):
     """float64 restatement of the epilogue chain of tlin.hip / wst.hip: bias -> ReLU -> dropout -> gate -> (+ previous) ->
     (+ residual) -> LayerNorm(eps 1e-5)."""
     M = X.shape[0]
-    Xe = bf(X)                                                              # fp32 activations are converted to bf16 on load
+    Xe = X.float().double() if exact else bf(X)                             # fp32 activations are converted to bf16 on load
     if film is not None:
         Xe = X.float().double()
         g, b, group = film
         idx = torch.arange(M) // group
-        Xe = bf((g.double()[idx] * Xe + b.double()[idx]).float())          # modulated in fp32, rounded to bf16 on the way to LDS
+        Xe = (g.double()[idx] * Xe + b.double()[idx]).float()              # modulated in fp32,
+        Xe = Xe.double() if exact else bf(Xe)                              # rounded to bf16 on the way to LDS (bf16x3: split, not rounded)
     y = Xe @ W.double().T
     if bias is not None:
         y = y + bias.double()
@@ -286,6 +287,34 @@ def test_token_on_lane_linear_kernels_equal_the_fp64_product(name):
     """Route 1 = the token-on-lane kernels (csrc/tlin.hip: tlin_str_kernel<256, XB, YB, EPI>, tlin_res16_kernel<PRE_*>) the same calls
     run on when no weight-stationary instantiation takes them (other widths, GG_NO_WST)."""
     _linear_case(name, 1)
+
+
+@pytest.mark.parametrize("name", list(LINEAR_CASES))
+def test_split_operand_linear_equals_the_fp64_product_of_the_fp32_operands(name):
+    """Route 2 = tlin3_kernel (csrc/tlin3.hip), the Linear of the bf16x3 parity mode: the same calls with fp32 activations,
+    fp32 weights and fp32 outputs; hi / lo bf16 splits, three MFMAs per tile.  NO operand rounding in the reference: the bound
+    is the fp32 one (1e-4; measured ~5e-6), three orders below what one bf16 operand rounding costs."""
+    build, _ = LINEAR_CASES[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % 1000 + 77)
+    kw = build(g)
+    kw["W"] = kw["W"] + 1e-3 * rnd(g, *kw["W"].shape).double()          # fp32 weights that are NOT bf16-representable
+    kw["X"] = kw["X"].float() + 1e-3 * rnd(g, *kw["X"].shape)
+    kw.update(x_bf16=False, y_bf16=False)
+    got, cls = run_linear(**kw, route=2)
+    want = ref_linear(**kw, exact=True)
+    diag(f"== Linear {name} (bf16x3, tlin3_kernel)")
+    M = kw["X"].shape[0]
+    yg = got["Y"].float().cpu()
+    if kw.get("y_row_group"):
+        grp = kw["y_row_group"]
+        rows = torch.arange(M) + torch.arange(M) // grp + 1
+        yg = yg[rows]
+    yr = kw["y_rows"] if kw.get("y_rows", -1) >= 0 else M
+    assert yr == M or torch.isnan(yg[yr:]).all()
+    check("Y", yg[:yr], want["Y"][:yr], False)
+    if "ln_y" in want:
+        check("LayerNorm output", got["ln_y"], want["ln_y"], False)
+        check("LayerNorm statistics (mean, rstd)", got["ln_stats"].cpu()[:yr], want["ln_stats"][:yr], False)
 
 
 # ---- fused self-attention ---------------------------------------------------------------------------------------------------
