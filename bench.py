@@ -47,7 +47,7 @@ def parse():
                          "vanilla: vanilla_gan_unconditional.py (configs[0]: --variant vanilla --batch 64 --genes 1000 --dropout 0)")
     ap.add_argument("--pad-frac", type=float, default=0.0,
                     help="fraction of samples whose last P/4 patch tokens are padded (SURVEY 8d masking run: 0.25)")
-    ap.add_argument("--precision", choices=["f32", "bf16", "fp8"], default="bf16",
+    ap.add_argument("--precision", choices=["f32", "bf16", "fp8", "bf16x3"], default="bf16",
                     help="GEMM arithmetic: bf16 = bf16 MFMA operands, fp32 accumulate (BASELINE north_star; headline), "
                          "f32 = exact fp32-input MFMA (the 1e-3 parity mode)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra f32 parity-mode timing (N=1 only)")

@@ -17,7 +17,7 @@ ROLE_GENERATOR, ROLE_CRITIC = 0, 1
 OPT_KINDS = {"rms_prop": 0, "adam": 1, "adamw": 2}
 LOSS_D_REAL, LOSS_D_FAKE, LOSS_GP, LOSS_G, N_LOSSES = 0, 1, 2, 3, 8
 LAY_KC, LAY_KS = 0, 1
-PRECISIONS = {"f32": 0, "bf16": 1, "fp8": 2}
+PRECISIONS = {"f32": 0, "bf16": 1, "fp8": 2, "bf16x3": 3}
 VARIANTS = {"xattn_film": 0, "film": 1, "img": 2, "vanilla": 3}      # GG_VARIANT_* (include/gemmgan.h)
 
 
@@ -124,7 +124,7 @@ SYMBOLS = {
                                    C.c_int64, C.c_void_p]),
     "gg_test_wgrad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
-                                C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+                                C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "gg_test_sqx_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]),
     "gg_test_sqx_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -2540,6 +2540,569 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream_kernel(const void*
     }
 }
 
+// ======================================================================================================
+// Split-operand ("bf16x3") attention for GG_PREC_BF16X3: fp32 tensors in memory, every MFMA operand as NS bf16 parts
+// (v = hi + lo (+ lo2)), each product tile as the 3 (NS = 2) or 6 (NS = 3) part products down to 2^-16 of the leading one,
+// fp32 accumulate.  Structure = the streaming row-major kernels above (resident tile per wave in registers, the other side
+// through double-buffered LDS chunks, transposed operands through ds_read_b64_tr_b16, same masks, same dropout stream), with
+// one LDS image per operand PART.  NS = 3 in the forward pass (fp32-grade context rows: they decide ReLU gates downstream),
+// NS = 2 in the backward kernels (see tlin3.hip).  A wave whose tile lies wholly past the end skips the arithmetic but
+// keeps staging (S = 257: the ninth query tile is one row).
+// ======================================================================================================
+template <int NS>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[NS]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) {
+        __bf16 b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)r[j];
+        const bf16x2_t w0 = {b[0], b[1]}, w1 = {b[2], b[3]}, w2 = {b[4], b[5]}, w3 = {b[6], b[7]};
+        const u32x4 w = {__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1), __builtin_bit_cast(unsigned, w2),
+                         __builtin_bit_cast(unsigned, w3)};
+        out[sp] = __builtin_bit_cast(bf16x8, w);
+        if (sp + 1 < NS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] -= (float)b[j];
+        }
+    }
+}
+template <int NS>
+__device__ __forceinline__ void split_acc(const f32x16& a, int s2, bf16x8 (&out)[NS]) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[8 * s2 + j];
+    split8<NS>(v, out);
+}
+// acc += a b over the part products, smallest terms first
+template <int NS>
+__device__ __forceinline__ void mma_parts(f32x16& acc, const bf16x8 (&a)[NS], const bf16x8 (&b)[NS]) {
+    if constexpr (NS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+// 8 consecutive fp32 values of a tensor as NS fragments
+template <int NS>
+__device__ __forceinline__ void load_parts(const float* p, bf16x8 (&out)[NS]) {
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    split8<NS>(v, out);
+}
+// one chunk (CK rows x DH columns of two fp32 operands) in flight: registers -> NS LDS images per operand
+template <int DH, int CK, int NS>
+struct ChunkRegs3 {
+    static constexpr int CPR = DH / 8, NP = CK * CPR / 256 > 0 ? CK * CPR / 256 : 1, LD = DH + 8, IMG = CK * LD;
+    f32x4 a[NP][2], b[NP][2];
+    __device__ __forceinline__ void load(const float* XA, long lda, const float* XB, long ldb, int row0, int S, int tid) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = min(tid + 256 * u, CK * CPR - 1);
+            const long row = min(row0 + p / CPR, S - 1);
+            const float* pa = XA + row * lda + 8 * (p % CPR);
+            const float* pb = XB + row * ldb + 8 * (p % CPR);
+            a[u][0] = *reinterpret_cast<const f32x4*>(pa); a[u][1] = *reinterpret_cast<const f32x4*>(pa + 4);
+            b[u][0] = *reinterpret_cast<const f32x4*>(pb); b[u][1] = *reinterpret_cast<const f32x4*>(pb + 4);
+        }
+    }
+    // images of part sp: A at As + sp * part_stride, B at Bs + sp * part_stride; rows >= S zero
+    __device__ __forceinline__ void store(__bf16* As, __bf16* Bs, int part_stride, int row0, int S, int tid) const {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = tid + 256 * u;
+            if (p < CK * CPR) {
+                const int row = p / CPR, c8 = p % CPR;
+                const bool in = row0 + row < S;
+                float va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j] = in ? a[u][0][j] : 0.f; va[4 + j] = in ? a[u][1][j] : 0.f;
+                    vb[j] = in ? b[u][0][j] : 0.f; vb[4 + j] = in ? b[u][1][j] : 0.f;
+                }
+                bf16x8 pa[NS], pb[NS];
+                split8<NS>(va, pa);
+                split8<NS>(vb, pb);
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {
+                    *reinterpret_cast<bf16x8*>(As + sp * part_stride + row * LD + 8 * c8) = pa[sp];
+                    *reinterpret_cast<bf16x8*>(Bs + sp * part_stride + row * LD + 8 * c8) = pb[sp];
+                }
+            }
+        }
+    }
+};
+template <int NS> struct X3Chunk { static constexpr int CK = NS == 3 ? 64 : 128; };
+// LDS: per part [2 buffers][2 operands][CK * (DH + 8)] bf16, then the key flags
+template <int NS>
+size_t x3_smem(int S, int DH, int ck = X3Chunk<NS>::CK) {
+    const int Sp = (S + 31) / 32 * 32;
+    return (size_t)NS * 4 * ck * (DH + 8) * 2 + Sp + 64 + 16;
+}
+
+template <int DH, int NS>
+__global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int mask_B,
+                                                            float* __restrict__ ctx, float* __restrict__ lse2, int S, int E, int nh,
+                                                            DropKey drop_in, int qkv_B, int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int CK = X3Chunk<NS>::CK;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = CK * LDK, PART = 4 * IMG;         // part sp: [buf][K | V][IMG]
+    __bf16* L0 = reinterpret_cast<__bf16*>(smem_raw);
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(L0 + NS * PART);
+    uint8_t* Mt = Ms + Sp;
+    constexpr int DT = (DH + 31) / 32, KS = DH / 16;
+
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* qb = qkv + (long)(n % qkv_B) * S * ld + hd * DH;
+    const long moff = (long)(n % mask_B) * S;
+    const int nkt = Sp / 32;
+    const int nchunks = (R + CK - 1) / CK;
+    const int qt = 4 * qg + wave;
+    const bool live = qt * 32 < S;                      // wave-uniform
+    const int q = qt * 32 + c;
+    const int qc = min(q, S - 1);
+
+    bf16x8 qf[KS][NS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) load_parts<NS>(qb + (long)qc * ld + 16 * s + 8 * h, qf[s]);
+    uint8_t mf[MASK_U];
+    mask_request<256>(mf, mask, moff, S, tid);
+    ChunkRegs3<DH, CK, NS> cr;
+    cr.load(qb + E, ld, qb + 2 * E, ld, 0, S, tid);
+    mask_flags<256>(Ms, Mt, mf, mask, moff, S, Sp, tid);
+    cr.store(L0, L0 + IMG, PART, 0, S, tid);
+    if (nchunks > 1) cr.load(qb + E, ld, qb + 2 * E, ld, CK, S, tid);
+    __syncthreads();
+
+    const float sc = rsqrtf((float)DH) * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    float m = -INFINITY, l = 0.f;
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+    const uint32_t srow = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+    TileOff toff;
+    toff.init(LDK, CK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) cr.store(L0 + (buf ^ 1) * 2 * IMG, L0 + (buf ^ 1) * 2 * IMG + IMG, PART, (ch + 1) * CK, S, tid);
+        if (ch + 2 < nchunks) cr.load(qb + E, ld, qb + 2 * E, ld, (ch + 2) * CK, S, tid);
+        const __bf16* Ks = L0 + buf * 2 * IMG;          // part sp at + sp * PART
+        const __bf16* Vs = Ks + IMG;
+        toff.rlim = min(CK, R - ch * CK) - 1;
+        const int kt_end = min(nkt, (ch + 1) * (CK / 32));
+        if (live)
+        for (int kt = ch * (CK / 32); kt < kt_end; ++kt) {
+            int tro[4], kro;
+            toff.tile((kt - ch * (CK / 32)) * 32, lane, tro, kro);
+            f32x16 s16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s16[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 kf[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) kf[sp] = *reinterpret_cast<const bf16x8*>(Ks + sp * PART + kro + 16 * s);
+                mma_parts<NS>(s16, kf, qf[s]);
+            }
+            float mt = -INFINITY;
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    s16[i] = Ms[key] ? -INFINITY : s16[i] * sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s16[i] *= sc;
+                    mt = fmaxf(mt, s16[i]);
+                }
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const bool move = mt > m + 8.f;            // lazy reference update, as in attn_fwd_kernel
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const float mn = move ? mt : m;
+                const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);
+                l *= alpha;
+                m = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+            }
+            const float mref = (m == -INFINITY) ? 0.f : m;
+            float lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = exp2f(s16[i] - mref);      // the accurate exponential: this kernel's results are held to fp32 grade
+                lt += p;
+                s16[i] = p;
+            }
+            lt += __shfl_xor(lt, 32, 64);
+            l += lt;
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    s16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? s16[4 * g + 0] : 0.f;
+                    s16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? s16[4 * g + 1] : 0.f;
+                    s16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? s16[4 * g + 2] : 0.f;
+                    s16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? s16[4 * g + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf[NS];
+                split_acc<NS>(s16, s2, pf);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x8 vf[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) vf[sp] = frag_tr_at(Vs + sp * PART, tro, s2, dt * 32);
+                    mma_parts<NS>(O[dt], vf, pf);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q < S) {
+        const float inv = ks / l;
+        const long out = ((long)n * S + q) * E + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 v = {O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv};
+                    *reinterpret_cast<f32x4*>(ctx + out + d) = v;
+                }
+            }
+        if (h == 0) lse2[(long)pair * S + q] = m + log2f(l);
+    }
+}
+
+// dQ: the wave's query tile (Q, dO parts, lse, delta in registers); K and V chunks stream
+template <int DH, int NS>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                               const float* __restrict__ dctx, const float* __restrict__ lse2,
+                                                               float* __restrict__ delta, const uint8_t* __restrict__ mask, int mask_B,
+                                                               float* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B,
+                                                               int npairs, int nqg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int CK = X3Chunk<NS>::CK;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = CK * LDK, PART = 4 * IMG;
+    __bf16* L0 = reinterpret_cast<__bf16*>(smem_raw);
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(L0 + NS * PART);
+    uint8_t* Mt = Ms + Sp;
+    constexpr int DT = (DH + 31) / 32, KS = DH / 16;
+
+    const int pair = ((int)(blockIdx.x >> 3) / nqg) * 8 + (int)(blockIdx.x & 7);
+    const int qg = (int)(blockIdx.x >> 3) % nqg;
+    if (pair >= npairs) return;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* qb = qkv + (long)(n % qkv_B) * S * ld + hd * DH;
+    const long moff = (long)(n % mask_B) * S;
+    const int nkt = Sp / 32;
+    const int nchunks = (R + CK - 1) / CK;
+    const int qt = 4 * qg + wave;
+    const bool live = qt * 32 < S;
+    const int q = qt * 32 + c;
+    const int qc = min(q, S - 1);
+
+    bf16x8 qf[KS][NS], df[KS][NS];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const long off = ((long)n * S + qc) * E + hd * DH + 16 * s + 8 * h;
+        load_parts<NS>(qb + (long)qc * ld + 16 * s + 8 * h, qf[s]);
+        float dv[8], ov[8];
+        load_f32x8<false>(dctx, off, dv);
+        load_f32x8<false>(ctx, off, ov);
+        split8<NS>(dv, df[s]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += dv[j] * ov[j];
+    }
+    const float L2raw = lse2[(long)pair * S + qc];
+    uint8_t mf[MASK_U];
+    mask_request<256>(mf, mask, moff, S, tid);
+    ChunkRegs3<DH, CK, NS> cr;
+    cr.load(qb + E, ld, qb + 2 * E, ld, 0, S, tid);
+    mask_flags<256>(Ms, Mt, mf, mask, moff, S, Sp, tid);
+    cr.store(L0, L0 + IMG, PART, 0, S, tid);
+    if (nchunks > 1) cr.load(qb + E, ld, qb + 2 * E, ld, CK, S, tid);
+    dl += __shfl_xor(dl, 32, 64);
+    if (q < S && h == 0) delta[(long)pair * S + q] = dl;      // consumed by the dK/dV kernel
+    const float L2 = q < S ? L2raw : 0.f;
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    f32x16 dQ[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+    const uint32_t srow = drop_state(drop, (((uint64_t)pair * S + (uint64_t)q) * (uint64_t)drop_attn_ld(S)) >> 1) + (uint32_t)(2 * h) * DROP_PHI;
+    TileOff toff;
+    toff.init(LDK, CK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) cr.store(L0 + (buf ^ 1) * 2 * IMG, L0 + (buf ^ 1) * 2 * IMG + IMG, PART, (ch + 1) * CK, S, tid);
+        if (ch + 2 < nchunks) cr.load(qb + E, ld, qb + 2 * E, ld, (ch + 2) * CK, S, tid);
+        const __bf16* Ks = L0 + buf * 2 * IMG;
+        const __bf16* Vs = Ks + IMG;
+        toff.rlim = min(CK, R - ch * CK) - 1;
+        const int kt_end = min(nkt, (ch + 1) * (CK / 32));
+        if (live)
+        for (int kt = ch * (CK / 32); kt < kt_end; ++kt) {
+            int tro[4], krow;
+            toff.tile((kt - ch * (CK / 32)) * 32, lane, tro, krow);
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 kf[NS], vf[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {
+                    kf[sp] = *reinterpret_cast<const bf16x8*>(Ks + sp * PART + krow + 16 * s);
+                    vf[sp] = *reinterpret_cast<const bf16x8*>(Vs + sp * PART + krow + 16 * s);
+                }
+                mma_parts<NS>(s16, kf, qf[s]);
+                mma_parts<NS>(dp16, vf, df[s]);
+            }
+            if (drop.p > 0.f) {
+                const uint32_t skt = srow + (uint32_t)(kt * 16) * DROP_PHI;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t b0 = drop_bits(skt + (uint32_t)(4 * g) * DROP_PHI), b1 = drop_bits(skt + (uint32_t)(4 * g + 1) * DROP_PHI);
+                    dp16[4 * g + 0] = drop_keep_even(b0, drop.thr) ? dp16[4 * g + 0] * ks : 0.f;
+                    dp16[4 * g + 1] = drop_keep_odd(b0, drop.thr) ? dp16[4 * g + 1] * ks : 0.f;
+                    dp16[4 * g + 2] = drop_keep_even(b1, drop.thr) ? dp16[4 * g + 2] * ks : 0.f;
+                    dp16[4 * g + 3] = drop_keep_odd(b1, drop.thr) ? dp16[4 * g + 3] * ks : 0.f;
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)Mt[kt])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + acc_row(i, h);
+                    const float p = Ms[key] ? 0.f : exp2f(__builtin_fmaf(s16[i], sc, -L2));
+                    s16[i] = p * (dp16[i] - dl);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s16[i] = exp2f(__builtin_fmaf(s16[i], sc, -L2)) * (dp16[i] - dl);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 sf[NS];
+                split_acc<NS>(s16, s2, sf);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x8 kf[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) kf[sp] = frag_tr_at(Ks + sp * PART, tro, s2, dt * 32);
+                    mma_parts<NS>(dQ[dt], kf, sf);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q < S) {
+        const long out = ((long)n * S + q) * ld + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 v = {dQ[dt][4 * g] * scale, dQ[dt][4 * g + 1] * scale, dQ[dt][4 * g + 2] * scale, dQ[dt][4 * g + 3] * scale};
+                    *reinterpret_cast<f32x4*>(dqkv + out + d) = v;
+                }
+            }
+    }
+}
+
+// dK / dV: the wave's key tile (K, V parts in registers); Q and dO chunks with their lse / delta rows stream (64-row chunks)
+template <int NS>
+size_t x3_dkv_smem(int DH) { return (size_t)NS * 4 * 64 * (DH + 8) * 2 + (size_t)4 * 64 * 4; }
+template <int DH, int NS>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                const uint8_t* __restrict__ mask, int mask_B, float* __restrict__ dqkv,
+                                                                int S, int E, int nh, DropKey drop_in, int qkv_B, int npairs, int nkg) {
+    const DropKey drop = drop_live(drop_in);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int CK = 64;
+    const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
+    constexpr int LDK = DH + 8, IMG = CK * LDK, PART = 4 * IMG;         // part sp: [buf][Q | dO][IMG]
+    __bf16* L0 = reinterpret_cast<__bf16*>(smem_raw);
+    float* Lb = reinterpret_cast<float*>(L0 + NS * PART);       // [2][CK] log-sum-exp rows of the chunk
+    float* Eb = Lb + 2 * CK;                                    // [2][CK] delta rows
+    constexpr int DT = (DH + 31) / 32, KS = DH / 16;
+
+    const int pair = ((int)(blockIdx.x >> 3) / nkg) * 8 + (int)(blockIdx.x & 7);
+    const int kg = (int)(blockIdx.x >> 3) % nkg;
+    if (pair >= npairs) return;
+    const long nhid = pair;
+    const int n = pair / nh, hd = pair % nh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ld = 3L * E;
+    const float* qb = qkv + (long)(n % qkv_B) * S * ld + hd * DH;
+    const float* db = dctx + (long)n * S * E + hd * DH;
+    const int nqt = Sp / 32;
+    const int nchunks = (R + CK - 1) / CK;
+    const int ktile = 4 * kg + wave;
+    const bool live = ktile * 32 < S;
+    const int key = ktile * 32 + c;
+    const int keyc = min(key, S - 1);                  // keys past the end re-read the last key: zeroed below, never stored
+    bf16x8 kf[KS][NS], vf[KS][NS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        load_parts<NS>(qb + (long)keyc * ld + E + 16 * s + 8 * h, kf[s]);
+        load_parts<NS>(qb + (long)keyc * ld + 2 * E + 16 * s + 8 * h, vf[s]);
+    }
+    const uint8_t mk = mask ? mask[(long)(n % mask_B) * S + keyc] : (uint8_t)0;
+    ChunkRegs3<DH, CK, NS> cr;
+    float lr = 0.f, er = 0.f;                          // this thread's lse / delta row of the chunk in flight (threads 0 .. CK-1)
+    auto load_chunk = [&](int row0) {
+        cr.load(qb, ld, db, (long)E, row0, S, tid);
+        const long r = nhid * S + min(row0 + (tid & (CK - 1)), S - 1);
+        lr = lse2[r];
+        er = delta[r];
+    };
+    auto store_chunk = [&](int b, int row0) {
+        cr.store(L0 + b * 2 * IMG, L0 + b * 2 * IMG + IMG, PART, row0, S, tid);
+        if (tid < CK) {
+            Lb[b * CK + tid] = row0 + tid < S ? lr : 0.f;
+            Eb[b * CK + tid] = row0 + tid < S ? er : 0.f;
+        }
+    };
+    load_chunk(0);
+    store_chunk(0, 0);
+    if (nchunks > 1) load_chunk(CK);
+    __syncthreads();
+
+    const float scale = rsqrtf((float)DH);
+    const float sc = scale * LOG2E;
+    const float ks = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    const uint64_t Sd = (uint64_t)drop_attn_ld(S);
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dK[dt][i] = 0.f; dV[dt][i] = 0.f; }
+    TileOff toff;
+    toff.init(LDK, CK - 1, lane);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1, (ch + 1) * CK);
+        if (ch + 2 < nchunks) load_chunk((ch + 2) * CK);
+        const __bf16* Qs = L0 + buf * 2 * IMG;
+        const __bf16* Ds = Qs + IMG;
+        const float* Ls = Lb + buf * CK;
+        const float* Dl = Eb + buf * CK;
+        toff.rlim = min(CK, R - ch * CK) - 1;
+        const int qt_end = min(nqt, (ch + 1) * (CK / 32));
+        if (live)
+        for (int qt = ch * (CK / 32); qt < qt_end; ++qt) {       // rows past the end are zero rows of Q and dO with lse = delta = 0
+            const int ql = (qt - ch * (CK / 32)) * 32;
+            int tro[4], qrow;
+            toff.tile(ql, lane, tro, qrow);
+            f32x16 s16, dp16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s16[i] = 0.f; dp16[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 qa[NS], da[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {
+                    qa[sp] = *reinterpret_cast<const bf16x8*>(Qs + sp * PART + qrow + 16 * s);
+                    da[sp] = *reinterpret_cast<const bf16x8*>(Ds + sp * PART + qrow + 16 * s);
+                }
+                mma_parts<NS>(s16, qa, kf[s]);          // S[q, key]: query rows in registers, the key on the lane
+                mma_parts<NS>(dp16, da, vf[s]);
+            }
+            f32x16 pd16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qr = ql + acc_row(i, h);             // row inside the chunk
+                const float p = exp2f(__builtin_fmaf(s16[i], sc, -Ls[qr]));
+                float km = 1.f;
+                if (drop.p > 0.f) km = drop_factor(drop, (nhid * (uint64_t)S + (uint64_t)(ch * CK + qr)) * Sd + (uint64_t)key, ks);
+                pd16[i] = p * km;
+                s16[i] = p * __builtin_fmaf(dp16[i], km, -Dl[qr]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf[NS], sf[NS];
+                split_acc<NS>(pd16, s2, pf);
+                split_acc<NS>(s16, s2, sf);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x8 dof[NS], qtf[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) {
+                        dof[sp] = frag_tr_at(Ds + sp * PART, tro, s2, dt * 32);
+                        qtf[sp] = frag_tr_at(Qs + sp * PART, tro, s2, dt * 32);
+                    }
+                    mma_parts<NS>(dV[dt], dof, pf);
+                    mma_parts<NS>(dK[dt], qtf, sf);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (key < S) {
+        const bool kvalid = !mk;
+        const float kz = kvalid ? scale : 0.f, vz = kvalid ? 1.f : 0.f;
+        const long outk = ((long)n * S + key) * ld + E + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                if (d < DH) {
+                    f32x4 a = {dK[dt][4 * g] * kz, dK[dt][4 * g + 1] * kz, dK[dt][4 * g + 2] * kz, dK[dt][4 * g + 3] * kz};
+                    f32x4 b = {dV[dt][4 * g] * vz, dV[dt][4 * g + 1] * vz, dV[dt][4 * g + 2] * vz, dV[dt][4 * g + 3] * vz};
+                    *reinterpret_cast<f32x4*>(dqkv + outk + d) = a;
+                    *reinterpret_cast<f32x4*>(dqkv + outk + E + d) = b;
+                }
+            }
+    }
+}
+
 size_t fwd_smem(int S, int DH) {
     const int Sp = (S + 31) / 32 * 32;
     return (size_t)Sp * (DH + 8) * 2 + (size_t)DH * (Sp + TPAD) * 2 + Sp + 64 + 16 + (size_t)3 * CO_MAXQ * (DH + 2) * 4;
@@ -2776,6 +3339,63 @@ int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const flo
     }
 #undef GG_BWD
 #undef GG_BWD_RM
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ---- split-operand (bf16x3) attention: fp32 tensors, ns operand parts (2: three products per tile, 3: six) ---------------------
+bool flash_attn_x3_supported(int S, int E, int nh) {
+    if (nh <= 0 || E % nh || E % 4) return false;
+    const int dh = E / nh;
+    return (dh == 16 || dh == 32 || dh == 64) && S >= 1 && S <= LONG_MAX_S;
+}
+const char* flash_attn_x3_kernel_name(int which) {
+    return which == 0 ? "attn_fwd_x3_kernel" : which == 1 ? "attn_bwd_dq_x3_kernel" : "attn_bwd_dkv_x3_kernel";
+}
+int flash_attn_fwd_x3(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
+                      DropKey drop, hipStream_t st, long qkv_B, int ns) {
+    GG_REQUIRE(flash_attn_x3_supported(S, E, nh) && (ns == 2 || ns == 3), "split-operand attention: unsupported shape");
+    const int qB = (int)(qkv_B > 0 ? qkv_B : N), dh = E / nh;
+    const int nqg = ((S + 31) / 32 + 3) / 4;
+    const dim3 grid((unsigned)(((N * nh + 7) / 8) * 8 * nqg));
+#define GG_F3(D, NS_)                                                                                                    \
+    do {                                                                                                               \
+        const size_t sm = x3_smem<NS_>(S, D);                                                                          \
+        GG_TRY(set_smem(&attn_fwd_x3_kernel<D, NS_>, sm));                                                              \
+        hipLaunchKernelGGL((attn_fwd_x3_kernel<D, NS_>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, (int)(N * nh), nqg); \
+    } while (0)
+    if (ns == 3) {
+        if (dh == 64) GG_F3(64, 3); else if (dh == 32) GG_F3(32, 3); else GG_F3(16, 3);
+    } else {
+        if (dh == 64) GG_F3(64, 2); else if (dh == 32) GG_F3(32, 2); else GG_F3(16, 2);
+    }
+#undef GG_F3
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int flash_attn_bwd_x3(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                      int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st, long qkv_B, int ns,
+                      hipEvent_t ev_mid) {
+    GG_REQUIRE(flash_attn_x3_supported(S, E, nh) && (ns == 2 || ns == 3), "split-operand attention: unsupported shape");
+    const int qB = (int)(qkv_B > 0 ? qkv_B : N), dh = E / nh;
+    const int ng = ((S + 31) / 32 + 3) / 4;
+    const dim3 grid((unsigned)(((N * nh + 7) / 8) * 8 * ng));
+#define GG_B3(D, NS_)                                                                                                    \
+    do {                                                                                                               \
+        const size_t sm = x3_smem<NS_>(S, D), smk = x3_dkv_smem<NS_>(D);                                                \
+        GG_TRY(set_smem(&attn_bwd_dq_x3_kernel<D, NS_>, sm));                                                           \
+        hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<D, NS_>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng); \
+        if (ev_mid) GG_CHECK_HIP(hipEventRecord(ev_mid, st));                                                           \
+        GG_TRY(set_smem(&attn_bwd_dkv_x3_kernel<D, NS_>, smk));                                                         \
+        hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<D, NS_>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng); \
+    } while (0)
+    if (ns == 3) {
+        if (dh == 64) GG_B3(64, 3); else if (dh == 32) GG_B3(32, 3); else GG_B3(16, 3);
+    } else {
+        if (dh == 64) GG_B3(64, 2); else if (dh == 32) GG_B3(32, 2); else GG_B3(16, 2);
+    }
+#undef GG_B3
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }

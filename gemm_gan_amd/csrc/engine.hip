@@ -47,6 +47,7 @@ struct Net {
     // bf16 shadow copies of the 2-D conditioning-stack weights (same offsets as the flat fp32 buffer):
     // wb = W [rows][cols], wtb = W^T [cols][rows]; refreshed from the fp32 master at every public entry
     char *wb = nullptr, *wtb = nullptr;
+    float* wt32 = nullptr;     // bf16x3 mode: fp32 W^T, same offsets
     // fp8 mode: e4m3 shadow of the same weights (tensor at byte offset 2 * flat offset), per-tensor exponents
     char* w8 = nullptr;
     unsigned* w8_amax = nullptr;
@@ -130,6 +131,7 @@ struct gg_engine {
     Net net[2];
     float dropout = 0.f;
     int precision = GG_PREC_F32;
+    bool x3 = false;           // GG_PREC_BF16X3: the bf16 mode's kernels on hi / lo splits of fp32 operands, fp32 storage (parity mode)
     bool fp8_fwd = false;      // GG_PREC_FP8: bf16 mode with e4m3 operands in the encoder layers' forward Linears
     bool xattn = true;         // text<->image cross attention (conditional_gan_cross_attention_with_film.py); false: CLS row (conditional_gan_film.py)
     bool enc_bias = true;      // encoder layers with biases (bias=False in conditional_gan_film.py:115)
@@ -395,6 +397,7 @@ size_t carve(gg_engine* e, void* base) {
         Net& n = e->net[r];
         n.wb = a.take<char>((size_t)n.total * 2);
         n.wtb = a.take<char>((size_t)n.total * 2);
+        n.wt32 = a.take<float>((size_t)n.total);
         n.tab_dev = a.take<ShadowEntry>(n.tab.size() + 1);
         n.w8 = a.take<char>((size_t)n.total * 2);
         n.w8_amax = a.take<unsigned>(n.tab.size() + 1);
@@ -494,7 +497,8 @@ struct ProfScope {
 int run_gemm(Ctx& c, const GemmP& p) {
     gg_engine* e = c.e;
     e->launches++;
-    const bool bf16 = e->precision == GG_PREC_BF16;
+    // bf16x3: the few-tile products (MLP heads, cross-attention projections, FiLM head) run on the exact fp32-input MFMA
+    const bool bf16 = e->precision == GG_PREC_BF16 && !e->x3;
     const bool small = bf16 && e->small_on && gemm_small_wanted(p);
     static const char* small_names[4] = {"gemm_small_kernel<0,0>", "gemm_small_kernel<0,1>", "gemm_small_kernel<1,0>", "gemm_small_kernel<1,1>"};
     const int cls_ = !e->prof_on ? 0 : small ? named_class(e, small_names[p.layA * 2 + p.layB]) : p.layA * 2 + p.layB + (bf16 ? 4 : 0);
@@ -572,7 +576,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
         e->launches++;
         gg_engine::ProfRec r;
         // classes follow the kernel instantiations: wgrad_kernel<dY bf16, X bf16, FiLM on the fly, FiLM gradient>
-        const int wcls = film ? 17 : (dy_bf16 ? (x_bf16 ? 15 : 10) : 16);
+        const int wcls = film ? 17 : (dy_bf16 ? (x_bf16 ? 15 : 10) : 16);      // (bf16x3: the fp32 / fp32 and FiLM instantiations with X3)
         const bool prof = e->prof_on && ((e->prof_mask >> wcls) & 1u);
         if (prof) {
             if (e->prof_next + 2 > e->prof_pool.size()) {
@@ -589,7 +593,7 @@ int lin_bwd_weight(Ctx& c, const float* dY, long ldy, const float* X, long ldx, 
             r.e1 = e->prof_pool[e->prof_next++];
             GG_CHECK_HIP(hipEventRecord(r.e0, c.st));
         }
-        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr, x_mod));
+        GG_TRY(wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, c.st, film, nullptr, dy_bf16 ? dbias : nullptr, x_mod, e->x3));
         if (dbias && !dy_bf16) { GG_TRY(k_colsum(dY, M, N, ldy, dbias, c.st, 0)); e->launches++; }
         if (prof) {
             GG_CHECK_HIP(hipEventRecord(r.e1, c.st));
@@ -619,6 +623,10 @@ inline bool use_tlin(gg_engine* e) { return e->tlin_on && e->precision == GG_PRE
 
 int refresh_shadows(Ctx& c, Net& n) {
     if (!use_tlin(c.e) || n.tab.empty()) return 0;
+    if (c.e->x3) {          // the split-operand Linears read the fp32 master weights; only W^T has to be made
+        KL(k_shadow_weights_t32(n.w, n.wt32, n.tab_dev, (int)n.tab.size(), c.st));
+        return 0;
+    }
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
     if (c.e->fp8_fwd) {
         GG_TRY(k_shadow_weights_fp8(n.w, n.w8, n.w8_amax, n.w8_exp, n.tab_dev, (int)n.tab.size(), c.st));
@@ -643,7 +651,50 @@ inline const void* WB(const Net& n, long off) { return n.wb + 2 * off; }      //
 inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    // bf16 W^T at flat offset `off`
 
 // launches the token-on-lane kernel when enabled and the shape qualifies; returns 1 if it ran
+// bf16x3: the call sites hand over bf16 shadow weights (W or W^T at the flat offset of the tensor); the split-operand kernel reads
+// the fp32 master copy / its fp32 transpose at the same offset
+// returns the number of operand parts: 3 (six products, fp32-grade) for a forward Linear (W: its results decide ReLU gates), 2 (three
+// products) for a backward one (W^T); 0: not a shadow pointer
+int x3_weights(gg_engine* e, TlinP& t) {
+    const char* w = reinterpret_cast<const char*>(t.W);
+    for (Net& n : e->net) {
+        if (n.wb && w >= n.wb && w < n.wb + 2 * (size_t)n.total) { t.W = n.w + (w - n.wb) / 2; return 3; }
+        if (n.wtb && w >= n.wtb && w < n.wtb + 2 * (size_t)n.total) { t.W = n.wt32 + (w - n.wtb) / 2; return 2; }
+    }
+    return 0;
+}
+int try_tlin3(Ctx& c, const TlinP& p_in) {
+    gg_engine* e = c.e;
+    TlinP p = p_in;
+    if (p.x_bf16 || p.y_bf16 || p.mask_bf16 || p.fp8) return 0;
+    const int ns = x3_weights(e, p);
+    if (!ns || !tlin3_supported(p)) return 0;
+    e->launches++;
+    const int cls = e->prof_on ? named_class(e, ns == 3 ? "tlin3_kernel<8,3>" : "tlin3_kernel<8,2>") : 0;
+    if (e->prof_on && prof_wanted(e, cls)) {
+        if (e->prof_next + 2 > e->prof_pool.size())
+            for (int i = 0; i < 4096; ++i) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return -1;
+                e->prof_pool.push_back(ev);
+            }
+        gg_engine::ProfRec r;
+        r.cls = cls;
+        r.flops = (ns == 3 ? 6.0 : 3.0) * 2.0 * p.M * p.N * (double)p.K;          // bf16 MFMA passes actually issued
+        const double MN = (double)p.M * p.N;
+        r.bytes = 4.0 * ((double)p.M * p.K + MN + (p.ln_g ? MN : 0.0) + (p.res ? MN : 0.0) + (p.accumulate ? MN : 0.0) + (p.mask_ref ? MN : 0.0) +
+                         (double)p.N * p.K);
+        r.e0 = e->prof_pool[e->prof_next++];
+        r.e1 = e->prof_pool[e->prof_next++];
+        tlin3_time_next(r.e0, r.e1);
+        if (tlin3(p, c.st, ns) != 0) return -1;
+        e->prof_recs.push_back(r);
+        return 1;
+    }
+    return tlin3(p, c.st, ns) == 0 ? 1 : -1;
+}
 int try_tlin(Ctx& c, const TlinP& p) {
+    if (use_tlin(c.e) && c.e->x3) return try_tlin3(c, p);
     if (!use_tlin(c.e) || !tlin_supported(p)) return 0;
     c.e->launches++;
     static const int tlin_cls[5] = {8, 9, 12, 13, 14};
@@ -776,11 +827,13 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     KL(k_write_cls(a.x0, w + n.cls, B, S, E, c.st));
     KL(k_build_mask(in->patch_pad, a.mask, B, P, c.st));
     const float scale = 1.f / sqrtf((float)dh);
-    const bool use_flash = e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(S, E, nh);
+    // bf16x3: the split-operand kernels (three operand parts in the forward pass, two in the backward one; any S <= 2048)
+    const bool use_flash3 = e->flash && e->precision == GG_PREC_BF16 && e->x3 && flash_attn_x3_supported(S, E, nh);
+    const bool use_flash = use_flash3 || (e->flash && e->precision == GG_PREC_BF16 && !e->x3 && flash_attn_supported(S, E, nh));
     a.flash = use_flash;
     // bf16 storage of the tensors that are only ever read as bf16 MFMA operands: every producer / consumer
     // must be a tlin / flash kernel, which holds for E in {64,128,256} (see tlin_supported)
-    const bool bst = e->bstore_on && use_flash && use_tlin(e) && (E == 64 || E == 128 || E == 256);
+    const bool bst = e->bstore_on && !e->x3 && use_flash && use_tlin(e) && (E == 64 || E == 128 || E == 256);
     a.bst = bst;
     // The replicas differ only by their dropout draws, and nothing is dropped before the first attention: the layer-0
     // input x0 and its QKV projection are the same for all of them.  With the fused kernels (row / sample indices taken
@@ -819,7 +872,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
         if (use_flash) {
             {   // algorithmic: packed QKV read once (B rows when layer 0 is shared by the replicas), context written once
                 const double tok = (double)RB * S, qtok = (share0 && l == 0 ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
-                ProfScope ps(c, flash_attn_kernel_name(0, S, E, nh), 4.0 * tok * S * E, es * (3.0 * qtok * E + tok * E) + 4.0 * tok * nh);
+                ProfScope ps(c, use_flash3 ? flash_attn_x3_kernel_name(0) : flash_attn_kernel_name(0, S, E, nh), (use_flash3 ? 6.0 : 1.0) * 4.0 * tok * S * E,
+                             es * (3.0 * qtok * E + tok * E) + 4.0 * tok * nh);
+                if (use_flash3) KL(flash_attn_fwd_x3(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, c.st, share0 && l == 0 ? B : 0, 3));
+                else
                 KL(flash_attn_fwd(L.qkv, a.mask, B, L.ctx, L.lse, RB, S, E, nh, kA, bst, c.st, share0 && l == 0 ? B : 0));
             }
         } else {
@@ -1227,7 +1283,11 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             {   // dQ kernel: reads QKV, O and dO (row dots), writes dQ; dK/dV kernel: reads QKV and dO, writes dK | dV
                 const double tok = (double)RB * S, qtok = (shared ? (double)B : (double)RB) * S, es = bst ? 2.0 : 4.0;
                 hipEvent_t mid = nullptr;
-                if (e->prof_on && (prof_wanted(e, named_class(e, flash_attn_kernel_name(1, S, E, nh))) || prof_wanted(e, named_class(e, flash_attn_kernel_name(2, S, E, nh))))) {
+                const bool f3 = e->x3;
+                const char* nm1 = f3 ? flash_attn_x3_kernel_name(1) : flash_attn_kernel_name(1, S, E, nh);
+                const char* nm2 = f3 ? flash_attn_x3_kernel_name(2) : flash_attn_kernel_name(2, S, E, nh);
+                const double fm = f3 ? 3.0 : 1.0;       // MFMA passes per product tile
+                if (e->prof_on && (prof_wanted(e, named_class(e, nm1)) || prof_wanted(e, named_class(e, nm2)))) {
                     if (e->prof_next + 1 > e->prof_pool.size())
                         for (int i = 0; i < 4096; ++i) {
                             hipEvent_t ev;
@@ -1236,8 +1296,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
                         }
                     mid = e->prof_pool[e->prof_next++];
                 }
-                ProfScope ps(c, flash_attn_kernel_name(2, S, E, nh), 8.0 * tok * S * E, es * (3.0 * qtok * E + tok * E + 2.0 * tok * E) + 8.0 * tok * nh);
-                ProfScope pq(c, flash_attn_kernel_name(1, S, E, nh), 6.0 * tok * S * E, es * (3.0 * qtok * E + 2.0 * tok * E + tok * E) + 8.0 * tok * nh);
+                ProfScope ps(c, nm2, fm * 8.0 * tok * S * E, es * (3.0 * qtok * E + tok * E + 2.0 * tok * E) + 8.0 * tok * nh);
+                ProfScope pq(c, nm1, fm * 6.0 * tok * S * E, es * (3.0 * qtok * E + 2.0 * tok * E + tok * E) + 8.0 * tok * nh);
+                if (f3) KL(flash_attn_bwd_x3(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, c.st, shared ? B : 0, 2, mid));
+                else
                 KL(flash_attn_bwd(L.qkv, L.ctx, e->sdctx, L.lse, e->s_delta, a.mask, B, e->sdqkv, RB, S, E, nh, kA, bst, c.st, shared ? B : 0, mid));
                 if (mid) {          // both scopes opened before the pair: dq = [pq.e0, mid], dkv = [mid, ps.e1]
                     if (pq.on) { pq.r.e1 = mid; e->prof_recs.push_back(pq.r); pq.on = false; }
@@ -1343,7 +1405,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         f.W = w + n.pe_w; f.ldw = Dp; f.dgamma = e->s_dgb; f.dbeta = e->s_dgb + Dp; f.ld = 2 * Dp; f.tokens = P;
         {
             ProfScope ps(c, "wgrad_kernel<false,false,false,true>", 2.0 * B * P * E * (double)Dp, 4.0 * B * P * ((double)E + Dp) + 4.0 * E * Dp);
-            KL(wgrad(e->s_demb, E, 0, in->patches, Dp, 0, nullptr, 0, (long)B * P, E, Dp, c.st, nullptr, &f));
+            KL(wgrad(e->s_demb, E, 0, in->patches, Dp, 0, nullptr, 0, (long)B * P, E, Dp, c.st, nullptr, &f, nullptr, 0, e->x3));
         }
     } else {
         TlinP t;
@@ -1622,7 +1684,8 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in, boo
     // first output is needed at once and is computed alone on the caller's stream; the others run on a third stream in
     // their own arena while the critic iterations that do not need them yet proceed.
     static const bool pipe_off = getenv("GG_NO_PREFETCH_PIPE") != nullptr;
-    bool pipe = !pipe_off && n > 1 && e->side_on && e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(in->P + 1, e->E, e->nh);
+    bool pipe = !pipe_off && n > 1 && e->side_on && e->flash && e->precision == GG_PREC_BF16 &&
+                (e->x3 ? flash_attn_x3_supported(in->P + 1, e->E, e->nh) : flash_attn_supported(in->P + 1, e->E, e->nh));
     // a critic conditioning pass computed ahead lives in the critic's arena: the generator passes take the spare one, in order
     const bool spare = e->dcond_valid;
     if (spare) pipe = false;
@@ -1683,7 +1746,8 @@ int generator_head_phase(Ctx& c, const float* z, const gg_cond* in, float* losse
     {
         Ctx cs = c;
         bool fk = false;
-        if (e->flash && e->precision == GG_PREC_BF16 && flash_attn_supported(in->P + 1, E, e->nh)) fk = side_begin(c, cs);
+        if (e->flash && e->precision == GG_PREC_BF16 &&
+            (e->x3 ? flash_attn_x3_supported(in->P + 1, E, e->nh) : flash_attn_supported(in->P + 1, E, e->nh))) fk = side_begin(c, cs);
         GG_TRY(cond_forward(cs, D, in, e->actsD, 1, e->dropout, 0));
         GG_TRY(side_end(c, fk, 3));
         GG_TRY(generator_forward(c, z, in, e->X2, 1));
@@ -1774,9 +1838,10 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
     e->dropout = cfg->dropout;
     e->seed = cfg->seed;
-    GG_REQUIRE(cfg->precision == GG_PREC_F32 || cfg->precision == GG_PREC_BF16 || cfg->precision == GG_PREC_FP8, "bad precision");
-    e->precision = cfg->precision == GG_PREC_FP8 ? GG_PREC_BF16 : cfg->precision;
+    GG_REQUIRE(cfg->precision >= GG_PREC_F32 && cfg->precision <= GG_PREC_BF16X3, "bad precision");
+    e->precision = cfg->precision == GG_PREC_F32 ? GG_PREC_F32 : GG_PREC_BF16;
     e->fp8_fwd = cfg->precision == GG_PREC_FP8;
+    e->x3 = cfg->precision == GG_PREC_BF16X3;
     build_net(e, GG_ROLE_GENERATOR);
     build_net(e, GG_ROLE_CRITIC);
     e->net[GG_ROLE_GENERATOR].lr = cfg->lr_g;
@@ -2015,7 +2080,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2132,9 +2197,12 @@ int gg_set_dropout(gg_engine* e, float p) {
     return 0;
 }
 int gg_set_precision(gg_engine* e, int precision) {
-    GG_REQUIRE(e && (precision == GG_PREC_F32 || precision == GG_PREC_BF16 || precision == GG_PREC_FP8), "bad precision");
-    e->precision = precision == GG_PREC_FP8 ? GG_PREC_BF16 : precision;
+    GG_REQUIRE(e && precision >= GG_PREC_F32 && precision <= GG_PREC_BF16X3, "bad precision");
+    e->precision = precision == GG_PREC_F32 ? GG_PREC_F32 : GG_PREC_BF16;
     e->fp8_fwd = precision == GG_PREC_FP8;
+    e->x3 = precision == GG_PREC_BF16X3;
+    e->dcond_valid = false;
+    e->pre_n = e->pre_next = 0;
     return 0;
 }
 int gg_set_side_streams(gg_engine* e, int on) {

@@ -146,6 +146,16 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
                    int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0, hipEvent_t ev_mid = nullptr);
 
+// split-operand (bf16x3) attention of GG_PREC_BF16X3: fp32 qkv / ctx / dctx / dqkv, `ns` bf16 parts per MFMA operand (2: three
+// products per tile - the backward form; 3: six products, fp32-grade - the forward form); any S <= 2048 (keys / queries streamed)
+bool flash_attn_x3_supported(int S, int E, int nh);
+const char* flash_attn_x3_kernel_name(int which);
+int flash_attn_fwd_x3(const float* qkv, const uint8_t* mask, int mask_B, float* ctx, float* lse2, long N, int S, int E, int nh,
+                      DropKey drop, hipStream_t st, long qkv_B, int ns);
+int flash_attn_bwd_x3(const float* qkv, const float* ctx, const float* dctx, const float* lse2, float* delta, const uint8_t* mask,
+                      int mask_B, float* dqkv, long N, int S, int E, int nh, DropKey drop, hipStream_t st, long qkv_B, int ns,
+                      hipEvent_t ev_mid = nullptr);
+
 // token-on-lane Linear (tlin.hip): Y[M,N] = epi(X[M,K] W[N,K]^T), bf16 MFMA, activations read once ---------------
 struct TlinP {
     const void* X = nullptr; long ldx = 0; long M = 0; int x_bf16 = 0;       // activations fp32 or bf16 (row stride in elements)
@@ -187,11 +197,13 @@ int tlin_kernel_class(const TlinP& p);
 // split-operand (bf16x3) Linear of GG_PREC_BF16X3 (tlin3.hip): same TlinP contract with fp32 X, fp32 W (the master copy, [N][K]),
 // fp32 Y and fp32 gate reference; three bf16 MFMAs per product tile on hi / lo splits, fp32 accumulate
 bool tlin3_supported(const TlinP& p);
-int tlin3(const TlinP& p, hipStream_t st);
+int tlin3(const TlinP& p, hipStream_t st, int nsplit = 2);      // nsplit 3: hi + mid + lo, six products (fp32-grade: forward passes)
 void tlin3_time_next(hipEvent_t begin, hipEvent_t end);
 // bf16 shadow copies of the 2-D weights: wb = bf16(W) [rows][cols], wtb = bf16(W^T) [cols][rows], same offsets
 struct ShadowEntry { long off; int rows, cols; };
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
+// bf16x3 mode: wt = W^T [cols][rows] in fp32 at the same offsets
+int k_shadow_weights_t32(const float* w, float* wt, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 // e4m3 shadow: w8[2*off + i] = e4m3(w[off + i] * 2^w_exp[entry]), w_exp[entry] = floor(log2(448 / max|w|)); amax: scratch [n_entries]
 int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 
@@ -222,7 +234,8 @@ struct WgradFilm { const float* g = nullptr; const float* b = nullptr; long ld =
 struct WgradFilmGrad { const float* W = nullptr; long ldw = 0; float* dgamma = nullptr; float* dbeta = nullptr; long ld = 0; int tokens = 0; };
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
           hipStream_t st, const WgradFilm* film = nullptr, const WgradFilmGrad* fgrad = nullptr, float* dbias = nullptr,
-          long x_mod = 0);        // x_mod > 0: X holds x_mod rows, row m is read at m % x_mod
+          long x_mod = 0, int x3 = 0);        // x_mod > 0: X holds x_mod rows, row m is read at m % x_mod
+// x3: split-operand (bf16x3) products of fp32 operands: hi / lo images in LDS, three MFMAs per tile (GG_PREC_BF16X3)
 // dbias (optional): dbias[n] += sum_m dY[m, n] with dY as the kernel sees it (bf16 operand values) - the Linear's bias gradient
 
 // optimiser ---------------------------------------------------------------------------------------

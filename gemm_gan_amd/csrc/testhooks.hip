@@ -31,10 +31,10 @@ int gg_test_linear(const gg_test_linear_args* a, int32_t* kernel_class, void* st
     p.accumulate = a->accumulate;
     p.res = a->res; p.ldres = a->ldres; p.res_rows = a->res_rows > 0 ? a->res_rows : 1;
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.ln_y = a->ln_y; p.ln_stats = a->ln_stats;
-    if (a->route == 2) {                // split-operand (bf16x3) Linear: fp32 X, fp32 W, fp32 Y
+    if (a->route == 2 || a->route == 3) {       // split-operand Linear: fp32 X, fp32 W, fp32 Y; 2 / 3 operand parts (3 / 6 products)
         GG_REQUIRE(tlin3_supported(p), "gg_test_linear: no bf16x3 instantiation for this call");
-        if (kernel_class) *kernel_class = 64;
-        return tlin3(p, (hipStream_t)stream);
+        if (kernel_class) *kernel_class = 62 + a->route;
+        return tlin3(p, (hipStream_t)stream, a->route);
     }
     GG_REQUIRE(tlin_supported(p), "gg_test_linear: the Linear kernels do not take this shape / alignment");
     tlin_force_route(a->route);
@@ -50,6 +50,11 @@ int gg_test_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx
                      float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_call, int io_bf16, int64_t qkv_B,
                      void* stream) {
     GG_REQUIRE(qkv && ctx && lse2, "null argument");
+    if (io_bf16 >= 2) {         // split-operand kernels: fp32 tensors, io_bf16 = number of operand parts (2 / 3)
+        GG_REQUIRE(flash_attn_x3_supported(S, E, nh), "gg_test_attn_fwd: unsupported shape");
+        return flash_attn_fwd_x3(reinterpret_cast<const float*>(qkv), mask, mask_B, reinterpret_cast<float*>(ctx), lse2, N, S, E, nh,
+                                 make_drop_key(drop_p, drop_seed, drop_site, drop_call), (hipStream_t)stream, qkv_B, io_bf16);
+    }
     GG_REQUIRE(flash_attn_supported(S, E, nh), "gg_test_attn_fwd: unsupported shape");
     return flash_attn_fwd(qkv, mask, mask_B, ctx, lse2, N, S, E, nh, make_drop_key(drop_p, drop_seed, drop_site, drop_call), io_bf16,
                           (hipStream_t)stream, qkv_B);
@@ -59,6 +64,12 @@ int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const f
                      int mask_B, void* dqkv, int64_t N, int S, int E, int nh, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                      uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream) {
     GG_REQUIRE(qkv && ctx && dctx && lse2 && delta && dqkv, "null argument");
+    if (io_bf16 >= 2) {
+        GG_REQUIRE(flash_attn_x3_supported(S, E, nh), "gg_test_attn_bwd: unsupported shape");
+        return flash_attn_bwd_x3(reinterpret_cast<const float*>(qkv), reinterpret_cast<const float*>(ctx), reinterpret_cast<const float*>(dctx),
+                                 lse2, delta, mask, mask_B, reinterpret_cast<float*>(dqkv), N, S, E, nh,
+                                 make_drop_key(drop_p, drop_seed, drop_site, drop_call), (hipStream_t)stream, qkv_B, io_bf16);
+    }
     GG_REQUIRE(flash_attn_supported(S, E, nh), "gg_test_attn_bwd: unsupported shape");
     return flash_attn_bwd(qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, N, S, E, nh,
                           make_drop_key(drop_p, drop_seed, drop_site, drop_call), io_bf16, (hipStream_t)stream, qkv_B, nullptr);
@@ -67,7 +78,7 @@ int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const f
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
                   int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,
-                  void* stream) {
+                  int x3, void* stream) {
     GG_REQUIRE(dY && X, "null argument");
     GG_REQUIRE(wgrad_supported(dY, ldy, dy_bf16, X, ldx, x_bf16, M, N, K), "gg_test_wgrad: the token-reduction kernel does not take this shape");
     WgradFilm film;
@@ -75,7 +86,7 @@ int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64
     WgradFilmGrad fg;
     fg.W = fgrad_W; fg.ldw = fgrad_ldw; fg.dgamma = dgamma; fg.dbeta = dbeta; fg.ld = fgrad_ld; fg.tokens = fgrad_tokens;
     return wgrad(dY, ldy, dy_bf16, X, ldx, x_bf16, dW, ldw, M, N, K, (hipStream_t)stream, film_g ? &film : nullptr,
-                 fgrad_W ? &fg : nullptr, dbias, x_mod);
+                 fgrad_W ? &fg : nullptr, dbias, x_mod, x3);
 }
 
 int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int mask_B, float* probs, float* xbar, int N, int S, int E,

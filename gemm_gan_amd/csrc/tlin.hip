@@ -856,6 +856,29 @@ __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ 
     }
 }
 
+// bf16x3 mode: fp32 W^T [cols][rows] at the same offsets (the data-gradient Linears read the transposed master weights)
+__global__ void shadow_t32_kernel(const float* __restrict__ w, float* __restrict__ wt, const ShadowEntry* __restrict__ tab) {
+    __shared__ float t[32][33];
+    const ShadowEntry e = tab[blockIdx.y];
+    const int tiles_c = (e.cols + 31) / 32, ntile = ((e.rows + 31) / 32) * tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            t[ty + 8 * k][tx] = (r < e.rows && c < e.cols) ? w[e.off + (long)r * e.cols + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < e.rows && c < e.cols) wt[e.off + (long)c * e.rows + r] = t[tx][ty + 8 * k];
+        }
+        __syncthreads();
+    }
+}
+
 // e4m3 shadow of the 2-D weights (forward orientation [rows][cols]) with one power-of-two scale per tensor:
 // pass 1: amax[entry] = max |w| (the bit pattern of a non-negative float orders like an unsigned integer);
 // pass 2: w_exp[entry] = floor(log2(448 / amax)) (the largest power of two that keeps the tensor inside the e4m3 range),
@@ -1070,6 +1093,13 @@ int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, c
     GG_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * n_entries, st));
     shadow8_amax_k<<<dim3(64, n_entries), 256, 0, st>>>(w, amax, tab_dev);
     shadow8_quant_k<<<dim3(64, n_entries), 256, 0, st>>>(w, reinterpret_cast<unsigned char*>(w8), amax, w_exp, tab_dev);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int k_shadow_weights_t32(const float* w, float* wt, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {
+    if (n_entries <= 0) return 0;
+    shadow_t32_kernel<<<dim3(64, n_entries), 256, 0, st>>>(w, wt, tab_dev);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -15,6 +15,12 @@
 // code.  Differences: K slices of 128 (two fragment sets per slice), weights read as fp32 from the master copy (no shadow),
 // column groups of <= 256 features in grid.y for the wide products (QKV 3 x 256, FFN1 2 x 256), run-time epilogue flags.
 // The engine's 1e-3 parity tests (tests/test_engine_golden_gpu.py, tests/test_engine_oracle_gpu.py) run in this mode.
+//
+// NS = 2 (above; 3 products): 2^-18 per operand, what the BACKWARD products run on.  NS = 3 splits v = hi + mid + lo (24 bits) and
+// adds the products down to 2^-16 of the leading one - hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi (6 products): fp32-grade
+// results (1e-7), which the FORWARD products need: a ReLU pre-activation that lands on the other side of zero switches that
+// unit's whole gradient contribution, and with 2^-18 operands that happens ~64 x as often as in fp32 (measured: one FFN gate
+// in ~10^6; visible in a small test as one weight-gradient row off by a token's contribution, harmless in training).
 #include "kernels.h"
 #include "drop_rng.h"
 #include <hip/hip_ext.h>
@@ -26,7 +32,8 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr float LN_EPS = 1e-5f;
-constexpr int KSL = 128, WLD = KSL + 8;
+// K slice per pass: 128 with two operand parts, 64 with three (the same 24 MFMAs per 32-feature chunk, half the fragment registers)
+template <int NS> struct Slice { static constexpr int KSL = NS == 3 ? 64 : 128, WLD = KSL + 8; };
 
 // v -> (hi, lo) pairs of two values, packed as bf16x2 words
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -44,11 +51,26 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
     lo = u32x2{l0, l1};
 }
 
+// NS-way split of four values into bf16x2 words: part 0 = hi, 1 = next 8 bits, 2 = next 8 bits
+template <int NS>
+__device__ __forceinline__ void splitn(const f32x4 v, u32x2 (&out)[NS]) {
+    f32x4 r = v;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const __bf16 b0 = (__bf16)r[0], b1 = (__bf16)r[1], b2 = (__bf16)r[2], b3 = (__bf16)r[3];
+        const bf16x2_t a = {b0, b1}, b = {b2, b3};
+        out[s] = u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+        if (s + 1 < NS) r = f32x4{r[0] - (float)b0, r[1] - (float)b1, r[2] - (float)b2, r[3] - (float)b3};
+    }
+}
+
 // rows [tok0, tok0 + 32) x [k0, k0 + KSL) of X (fp32, FiLM optional) as hi / lo bf16 images into the wave-private slabs
-__device__ __forceinline__ void stage_x3(const TlinP& p, __bf16* xh, __bf16* xl, int tok0, int last_tok, int k0, int lane) {
+template <int NS>
+__device__ __forceinline__ void stage_x3(const TlinP& p, __bf16* xs, int tok0, int last_tok, int k0, int lane) {   // xs: NS images, 4 * 32 * WLD apart
+    constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
     asm volatile("" : "+v"(tok0));
     const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
-    constexpr int LPR = KSL / 4, RPI = 64 / LPR, NLD = 32 / RPI, GB = 8;      // 32 lanes per row, 2 rows per instruction, 16 loads
+    constexpr int LPR = KSL / 4, RPI = 64 / LPR, NLD = 32 / RPI, GB = NLD < 8 ? NLD : 8;      // KSL 128: 2 rows per instruction, 16 loads in two batches
     const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
     const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
     f32x4 ga = {1.f, 1.f, 1.f, 1.f}, ba = {0.f, 0.f, 0.f, 0.f}, gb = ga, bb = ba;
@@ -83,27 +105,27 @@ __device__ __forceinline__ void stage_x3(const TlinP& p, __bf16* xh, __bf16* xl,
                 const bool second = rem0 + (r - tb) >= p.film_group;
                 m = (second ? gb : ga) * m + (second ? bb : ba);
             }
-            u32x2 hi, lo;
-            split4(m, hi, lo);
+            u32x2 parts[NS];
+            splitn<NS>(m, parts);
             const int o = (RPI * (b0 + i) + lrow) * WLD + lcol;
-            *reinterpret_cast<u32x2*>(&xh[o]) = hi;
-            *reinterpret_cast<u32x2*>(&xl[o]) = lo;
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x2*>(&xs[sp * (4 * 32 * WLD) + o]) = parts[sp];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int NT_RES>
+template <int NT_RES, int NS>
 __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
+    constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
     constexpr int N = 32 * NT_RES;                     // columns of this workgroup's group
     constexpr int WLOADS = 32 * (KSL / 4) / 256;       // float4 pieces per thread and weight chunk (4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* const Wh = reinterpret_cast<__bf16*>(smem_raw);                 // [2][32*WLD]
-    __bf16* const Wl = Wh + 2 * 32 * WLD;                                   // [2][32*WLD]
-    __bf16* const Xh = Wl + 2 * 32 * WLD;                                   // [4][32*WLD]
-    __bf16* const Xl = Xh + 4 * 32 * WLD;                                   // [4][32*WLD]
-    float* const Ps = reinterpret_cast<float*>(Xl + 4 * 32 * WLD);          // bias | gamma | beta  [3][N]
+    constexpr int WIMG = 2 * 32 * WLD, XIMG = 4 * 32 * WLD;                 // elements per weight / activation image (one split part)
+    __bf16* const Wsp = reinterpret_cast<__bf16*>(smem_raw);                // [NS][2][32*WLD]
+    __bf16* const Xsp = Wsp + NS * WIMG;                                    // [NS][4][32*WLD]
+    float* const Ps = reinterpret_cast<float*>(Xsp + NS * XIMG);            // bias | gamma | beta  [3][N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
@@ -112,8 +134,7 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const int last_tok = (int)p.M - 1;
     const int nks = p.K / KSL;
     const int nchunks = nks * NT_RES;
-    __bf16* const xh = Xh + wave * 32 * WLD;
-    __bf16* const xl = Xl + wave * 32 * WLD;
+    __bf16* const xs = Xsp + wave * 32 * WLD;          // this wave's slab of part 0; part sp at + sp * XIMG
 
     // weight chunks (32 output features x KSL, fp32) travel L2 -> registers -> (split) -> LDS two chunks ahead of their use
     f32x4 wreg[2][WLOADS];
@@ -131,10 +152,10 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
         for (int i = 0; i < WLOADS; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (KSL / 4), piece = f % (KSL / 4);
-            u32x2 hi, lo;
-            split4(wreg[set][i], hi, lo);
-            *reinterpret_cast<u32x2*>(&Wh[set * 32 * WLD + row * WLD + 4 * piece]) = hi;
-            *reinterpret_cast<u32x2*>(&Wl[set * 32 * WLD + row * WLD + 4 * piece]) = lo;
+            u32x2 parts[NS];
+            splitn<NS>(wreg[set][i], parts);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x2*>(&Wsp[sp * WIMG + set * 32 * WLD + row * WLD + 4 * piece]) = parts[sp];
         }
     };
 
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const bool has_pre = resp != nullptr || p.accumulate != 0;
 
     f32x16 acc[NT_RES];
-    bf16x8 xfh[KSL / 16], xfl[KSL / 16];
+    bf16x8 xf[NS][KSL / 16];
     // epilogue operands (residual rows / previous output, gate reference) travel one feature tile ahead of their use: tile 0 is
     // requested before the last MFMA pass, tile nt + 1 while tile nt is finished (all of them up front cost 128 registers: spills)
     f32x4 pre[2][4], mrf[2][4];
@@ -176,15 +197,14 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
-        stage_x3(p, xh, xl, tok0, last_tok, ks * KSL, lane);
+        stage_x3<NS>(p, xs, tok0, last_tok, ks * KSL, lane);
         if (ks == nks - 1) load_pre(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < KSL / 16; ++s) {
-            xfh[s] = *reinterpret_cast<const bf16x8*>(&xh[c * WLD + 16 * s + 8 * h]);
-            xfl[s] = *reinterpret_cast<const bf16x8*>(&xl[c * WLD + 16 * s + 8 * h]);
-        }
+        for (int s = 0; s < KSL / 16; ++s)
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) xf[sp][s] = *reinterpret_cast<const bf16x8*>(&xs[sp * XIMG + c * WLD + 16 * s + 8 * h]);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __syncthreads();     // chunk `chunk` is in W?[chunk & 1] (and Ps on the first pass)
@@ -197,16 +217,21 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             }
-            const __bf16* whb = Wh + buf * 32 * WLD + c * WLD + 8 * h;
-            const __bf16* wlb = Wl + buf * 32 * WLD + c * WLD + 8 * h;
+            const __bf16* wb0 = Wsp + buf * 32 * WLD + c * WLD + 8 * h;
 #pragma unroll
             for (int s = 0; s < KSL / 16; ++s) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whb + 16 * s);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlb + 16 * s);
+                bf16x8 wf[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) wf[sp] = *reinterpret_cast<const bf16x8*>(wb0 + sp * WIMG + 16 * s);
                 // small terms first, the leading product last
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xfh[s], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xfl[s], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xfh[s], acc[nt], 0, 0, 0);
+                if constexpr (NS == 3) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[0][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[1][s], acc[nt], 0, 0, 0);
+                }
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[0][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0][s], acc[nt], 0, 0, 0);
             }
             if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
             __syncthreads();
@@ -291,20 +316,21 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 
 hipEvent_t g3_ev0 = nullptr, g3_ev1 = nullptr;
 
-template <int NT_RES>
+template <int NT_RES, int NS>
 int launch3(const TlinP& p, int groups, hipStream_t st) {
-    constexpr size_t smem = (size_t)(2 * 2 + 2 * 4) * 32 * WLD * 2 + (size_t)3 * 32 * NT_RES * 4;
+    constexpr size_t smem = (size_t)NS * (2 + 4) * 32 * Slice<NS>::WLD * 2 + (size_t)3 * 32 * NT_RES * 4;
+    static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin3_kernel<NT_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin3_kernel<NT_RES, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)groups);
     if (g3_ev0) {
-        hipExtLaunchKernelGGL(tlin3_kernel<NT_RES>, grid, dim3(256), (unsigned)smem, st, g3_ev0, g3_ev1, 0, p);
+        hipExtLaunchKernelGGL((tlin3_kernel<NT_RES, NS>), grid, dim3(256), (unsigned)smem, st, g3_ev0, g3_ev1, 0, p);
         g3_ev0 = g3_ev1 = nullptr;
     } else {
-        hipLaunchKernelGGL(tlin3_kernel<NT_RES>, grid, dim3(256), smem, st, p);
+        hipLaunchKernelGGL((tlin3_kernel<NT_RES, NS>), grid, dim3(256), smem, st, p);
     }
     GG_CHECK_HIP(hipGetLastError());
     return 0;
@@ -318,7 +344,7 @@ void tlin3_time_next(hipEvent_t begin, hipEvent_t end) { g3_ev0 = begin; g3_ev1 
 bool tlin3_supported(const TlinP& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (double)p.M * (double)p.ldx * 4.0 >= 4.0e9) return false;      // 32-bit row offsets
     if (p.x_bf16 || p.y_bf16 || p.fp8 || (p.mask_ref && p.mask_bf16)) return false;
-    if (p.K % KSL) return false;
+    if (p.K % 128) return false;
     if (!(p.N == 64 || p.N == 128 || p.N == 256 || (p.N > 256 && p.N % 256 == 0))) return false;
     if (p.ln_g && (p.N > 256 || !p.ln_b || !p.ln_y || !p.ln_stats || !al16(p.ln_y))) return false;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % 4 || p.ldy % 4 || p.ldw % 4) return false;
@@ -329,11 +355,17 @@ bool tlin3_supported(const TlinP& p) {
     return true;
 }
 
-int tlin3(const TlinP& p, hipStream_t st) {
+int tlin3(const TlinP& p, hipStream_t st, int nsplit) {
     GG_REQUIRE(tlin3_supported(p), "tlin3: unsupported shape / alignment");
-    if (p.N == 64) return launch3<2>(p, 1, st);
-    if (p.N == 128) return launch3<4>(p, 1, st);
-    return launch3<8>(p, p.N / 256, st);
+    GG_REQUIRE(nsplit == 2 || nsplit == 3, "tlin3: 2 (hi, lo: 3 products) or 3 (hi, mid, lo: 6 products) operand parts");
+    if (nsplit == 3) {
+        if (p.N == 64) return launch3<2, 3>(p, 1, st);
+        if (p.N == 128) return launch3<4, 3>(p, 1, st);
+        return launch3<8, 3>(p, p.N / 256, st);
+    }
+    if (p.N == 64) return launch3<2, 2>(p, 1, st);
+    if (p.N == 128) return launch3<4, 2>(p, 1, st);
+    return launch3<8, 2>(p, p.N / 256, st);
 }
 
 }  // namespace gg

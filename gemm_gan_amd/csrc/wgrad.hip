@@ -25,6 +25,16 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// bf16x3 mode (X3): an fp32 value v is staged as hi = bf16(v) and lo = bf16(v - hi) in two LDS images; a product tile is
+// hi*hi + lo*hi + hi*lo (fp32-grade: 2^-16 relative), see tlin3.hip
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+    const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+    const bf16x2_t a = {h0, h1}, b = {h2, h3};
+    const bf16x2_t c = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1)}, d = {(__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+    hi = u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    lo = u32x2{__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+}
+
 // (tools/wgrad_probe.hip rebuilds this file with other values; measured alternatives are listed in DESIGN.md section 3)
 #ifndef GG_WG_WT
 #define GG_WG_WT 1
@@ -137,17 +147,24 @@ struct Stager {
         fgb = *reinterpret_cast<const f32x4*>(fg + g1 * fld + col0 + cc);
         fbb = *reinterpret_cast<const f32x4*>(fb + g1 * fld + col0 + cc);
     }
-    __device__ __forceinline__ void store_film(__bf16* img, int ld, int tid) const {
+    __device__ __forceinline__ void store_film(__bf16* img, int ld, int tid, __bf16* img_lo = nullptr) const {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
             const bool second = row >= fsplit;
             const f32x4 v = (second ? fgb : fga) * __builtin_bit_cast(f32x4, r[i]) + (second ? fbb : fba);
-            u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+            if (img_lo) {
+                u32x2 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = hi;
+                *reinterpret_cast<u32x2*>(img_lo + row * ld + 4 * pc) = lo;
+            } else {
+                u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+            }
         }
     }
-    __device__ __forceinline__ void store(__bf16* img, int ld, int tid, unsigned zmask = 0) const {
+    __device__ __forceinline__ void store(__bf16* img, int ld, int tid, unsigned zmask = 0, __bf16* img_lo = nullptr) const {
         if constexpr (BF) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -159,8 +176,15 @@ struct Stager {
             for (int i = 0; i < NP; ++i) {
                 const int f = tid + NT * i, row = f / PPR, pc = f % PPR;
                 const f32x4 v = ((zmask >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, r[i]);
-                u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+                if (img_lo) {
+                    u32x2 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = hi;
+                    *reinterpret_cast<u32x2*>(img_lo + row * ld + 4 * pc) = lo;
+                } else {
+                    u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(img + row * ld + 4 * pc) = w;
+                }
             }
         }
     }
@@ -172,13 +196,17 @@ struct Stager {
 // the Linear W, without materialising d(X') = dY W  (dgamma = sum_tokens dX' * X, dbeta = sum_tokens dX').
 // W8: eight waves per workgroup (two per SIMD) on the same 128 x 256 panel - wave (wn, wk) owns 32 rows x 128 columns (4 accumulator
 // tiles, half the staging registers per thread): while one wave of a SIMD waits for its LDS fragments the other multiplies.
-template <bool YB, bool XB, bool FILM, bool FGRAD, bool FAST, bool W8 = false>
+template <bool YB, bool XB, bool FILM, bool FGRAD, bool FAST, bool W8 = false, bool X3 = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const void* __restrict__ dY, long ldy, const void* __restrict__ X, long ldx,
                                                     float* __restrict__ dW, long ldw, long M, int N, int K, int splits, WgradFilm film,
                                                     WgradFilmGrad fg, float* __restrict__ dbias, long x_mod) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wg_smem[];       // 67.6 KB: above the static-LDS limit
+    static_assert(!X3 || (!YB && !XB), "bf16x3: fp32 operands");
     auto Ysb = [&](int b) { return wg_smem + b * (CT * LDY); };
     auto Xsb = [&](int b) { return wg_smem + 2 * (CT * LDY) + b * (CT * LDX); };
+    // bf16x3: the lo images behind the hi ones (null otherwise: the stagers then write one image)
+    auto Ysl = [&](int b) { return X3 ? wg_smem + 2 * CT * (LDY + LDX) + b * (CT * LDY) : (__bf16*)nullptr; };
+    auto Xsl = [&](int b) { return X3 ? wg_smem + 2 * CT * (LDY + LDX) + 2 * (CT * LDY) + b * (CT * LDX) : (__bf16*)nullptr; };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
     const int panels_k = (K + PK - 1) / PK;
@@ -246,12 +274,20 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
     auto multiply = [&](int buf) {
 #pragma unroll
         for (int s2 = 0; s2 < ((GG_WG_ABL & 1) ? 0 : CT / 16); ++s2) {
-            bf16x8 af[TA];
+            bf16x8 af[TA], al[X3 ? TA : 1];
 #pragma unroll
             for (int a = 0; a < TA; ++a) af[a] = frag_tr(Ysb(buf), LDY, nb + a * 32, s2, lane);
+            if constexpr (X3) {
+#pragma unroll
+                for (int a = 0; a < TA; ++a) al[a] = frag_tr(Ysl(buf), LDY, nb + a * 32, s2, lane);
+            }
             if (FGRAD || do_bias) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)af[0][j] << 16);
+                if constexpr (X3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ssum += __builtin_bit_cast(float, (unsigned)(unsigned short)al[0][j] << 16);
+                }
                 if constexpr (T22) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ssum2 += __builtin_bit_cast(float, (unsigned)(unsigned short)af[1][j] << 16);
@@ -260,6 +296,14 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 const bf16x8 bf = frag_tr(Xsb(buf), LDX, kb + b * 32, s2, lane);
+                if constexpr (X3) {
+                    const bf16x8 bl = frag_tr(Xsl(buf), LDX, kb + b * 32, s2, lane);
+#pragma unroll
+                    for (int a = 0; a < TA; ++a) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bf, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bl, acc[a][b], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < TA; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a][b], 0, 0, 0);
             }
@@ -288,13 +332,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
             ++issued;
         };
         auto to_lds = [&](int st, int buf) {
-            sy[st].store(Ysb(buf), LDY, tid, zmy);
+            sy[st].store(Ysb(buf), LDY, tid, zmy, Ysl(buf));
             if constexpr (GG_WG_ABL & 2) {
                 u32x4 t = sx[st].r[0];
                 for (int i = 1; i < Stager<XB, PK, NT>::NP; ++i) t |= sx[st].r[i];
                 if (t[0] == 0x12345678u) sx[st].store(Xsb(buf), LDX, tid);
-            } else if constexpr (FILM) sx[st].store_film(Xsb(buf), LDX, tid);
-            else sx[st].store(Xsb(buf), LDX, tid);
+            } else if constexpr (FILM) sx[st].store_film(Xsb(buf), LDX, tid, Xsl(buf));
+            else sx[st].store(Xsb(buf), LDX, tid, 0, Xsl(buf));
         };
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(sy[d], sx[d]);
@@ -321,9 +365,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
             if constexpr (FILM) sx[d].load_film(film.g, film.b, film.ld, film.group, (c_beg + d) * CT, M, k0, kvalid, tid);
         }
     }
-    sy[0].store(Ysb(0), LDY, tid);
-    if constexpr (FILM) sx[0].store_film(Xsb(0), LDX, tid);
-    else sx[0].store(Xsb(0), LDX, tid);
+    sy[0].store(Ysb(0), LDY, tid, 0, Ysl(0));
+    if constexpr (FILM) sx[0].store_film(Xsb(0), LDX, tid, Xsl(0));
+    else sx[0].store(Xsb(0), LDX, tid, 0, Xsl(0));
     __syncthreads();
     for (long r0 = 0; r0 < nch; r0 += DEPTH) {
 #pragma unroll
@@ -338,9 +382,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
                 }
                 multiply(buf);
                 if (r + 1 < nch) {
-                    sy[(u + 1) % DEPTH].store(Ysb(buf ^ 1), LDY, tid);
-                    if constexpr (FILM) sx[(u + 1) % DEPTH].store_film(Xsb(buf ^ 1), LDX, tid);
-                    else sx[(u + 1) % DEPTH].store(Xsb(buf ^ 1), LDX, tid);
+                    sy[(u + 1) % DEPTH].store(Ysb(buf ^ 1), LDY, tid, 0, Ysl(buf ^ 1));
+                    if constexpr (FILM) sx[(u + 1) % DEPTH].store_film(Xsb(buf ^ 1), LDX, tid, Xsl(buf ^ 1));
+                    else sx[(u + 1) % DEPTH].store(Xsb(buf ^ 1), LDX, tid, 0, Xsl(buf ^ 1));
                 }
                 __syncthreads();
             }
@@ -433,7 +477,8 @@ bool wgrad_supported(const void* dY, long ldy, int dy_bf16, const void* X, long 
 }
 
 int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_bf16, float* dW, long ldw, long M, int N, int K,
-          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in, float* dbias, long x_mod) {
+          hipStream_t st, const WgradFilm* film_in, const WgradFilmGrad* fgrad_in, float* dbias, long x_mod, int x3) {
+    GG_REQUIRE(!x3 || (!dy_bf16 && !x_bf16), "wgrad: the split-operand (bf16x3) form takes fp32 operands");
     WgradFilm film;
     if (film_in) film = *film_in;
     WgradFilmGrad fgrad;
@@ -468,6 +513,26 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
         }                                                                                                              \
         hipLaunchKernelGGL((wgrad_kernel<YB, XB, FL, FG, FA, W8_>), grid, dim3(W8_ ? 512 : 256), SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
     } while (0)
+    // bf16x3: fp32 operands, hi + lo images (2 x the LDS), eight waves when the loader is the branch-free one
+#define GG_WG3(FL, FG)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr3f = false, attr3g = false;                                                                    \
+        if (fast) {                                                                                                    \
+            if (!attr3f) GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<false, false, FL, FG, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SMEM)); \
+            hipLaunchKernelGGL((wgrad_kernel<false, false, FL, FG, true, true, true>), grid, dim3(512), 2 * SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
+        } else {                                                                                                       \
+            if (!attr3g) GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<false, false, FL, FG, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SMEM)); \
+            hipLaunchKernelGGL((wgrad_kernel<false, false, FL, FG, false, false, true>), grid, dim3(256), 2 * SMEM, st, dY, ldy, X, ldx, dW, ldw, M, N, K, splits, film, fgrad, dbias, x_mod); \
+        }                                                                                                              \
+        (fast ? attr3f : attr3g) = true;                                                                               \
+    } while (0)
+    if (x3) {
+        if (fgrad.W) GG_WG3(false, true);
+        else if (film.g) GG_WG3(true, false);
+        else GG_WG3(false, false);
+        GG_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define GG_WG(YB, XB, FL, FG)                  \
     do {                                       \
         if (fast && w8) GG_WG1(YB, XB, FL, FG, true, true); \
@@ -485,6 +550,7 @@ int wgrad(const void* dY, long ldy, int dy_bf16, const void* X, long ldx, int x_
     else GG_WG(false, false, false, false);
 #undef GG_WG
 #undef GG_WG1
+#undef GG_WG3
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -34,6 +34,9 @@ extern "C" {
 /* arithmetic of the GEMM-shaped products (everything else is fp32 in both modes) */
 #define GG_PREC_F32 0  /* fp32-input MFMA: exact fp32, the parity mode (<= 1e-3 vs the reference) */
 #define GG_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate: the throughput mode               */
+#define GG_PREC_BF16X3 3 /* split-operand bf16: every fp32 operand as hi + lo bf16 halves, three bf16 MFMAs per product tile, fp32  */
+                         /* accumulate and fp32 storage everywhere - fp32-grade results (<= 1e-3 vs the reference, the parity */
+                         /* gates run in it) through the token-on-lane Linear, fused attention and weight-gradient kernels     */
 #define GG_PREC_FP8 2  /* GG_PREC_BF16 with OCP e4m3 operands (block-scaled v_mfma_scale_f32_*_f8f6f4, fp32 accumulate,    */
                        /* per-tensor power-of-two scales) in the forward Linears of the encoder layers: BASELINE configs[4] */
 
@@ -236,11 +239,14 @@ typedef struct gg_test_linear_args {     /* Y = epi(X W^T): the encoder-layer Li
     const float* res; int64_t ldres; int64_t res_rows;           /* + res[row % res_rows]                                      */
     const float* ln_g; const float* ln_b; float* ln_y; float* ln_stats;                  /* LayerNorm of the sum (eps 1e-5)    */
     int32_t route;     /* 0: as the engine routes it (weight-stationary kernel when one takes the shape), 1: token-on-lane kernels only,
-                          2: the split-operand (bf16x3) Linear of GG_PREC_BF16X3                                                    */
+                          2 / 3: the split-operand Linear of GG_PREC_BF16X3 with 2 (hi, lo: three products, the backward form) /
+                          3 (hi, mid, lo: six products, the forward form) operand parts; W is then the fp32 matrix                  */
 } gg_test_linear_args;
 int gg_test_linear(const gg_test_linear_args* a, int32_t* kernel_class, void* stream);
 /* fused self-attention (torch functional.py:6206-6660): qkv [qkv_B or N, S, 3E] packed, mask [mask_B, S] bytes, ctx [N, S, E],
- * lse2 [N, nh, S] (log2-sum-exp of the scaled scores); backward: dctx -> dqkv [N, S, 3E], delta [N, nh, S] scratch */
+ * lse2 [N, nh, S] (log2-sum-exp of the scaled scores); backward: dctx -> dqkv [N, S, 3E], delta [N, nh, S] scratch.
+ * io_bf16: 0 fp32 tensors / 1 bf16 tensors through the bf16 kernels; 2 / 3: fp32 tensors through the split-operand kernels of
+ * GG_PREC_BF16X3 with that many bf16 parts per MFMA operand */
 const char* gg_test_attn_kernel_name(int which, int S, int E, int nh);     /* 0 forward, 1 dQ, 2 dK|dV */
 int gg_test_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, float* lse2, int64_t N, int S, int E, int nh,
                      float drop_p, uint64_t drop_seed, uint32_t drop_site, uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream);
@@ -251,7 +257,7 @@ int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const f
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
                   int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,
-                  void* stream);
+                  int x3 /* split-operand (bf16x3) products of fp32 operands */, void* stream);
 /* projection-free single-query attention sweeps (R:218-219 restated): qt [N,nh,E], x [N,S,E] -> probs [N,nh,S], xbar [N,nh,E] */
 int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int mask_B, float* probs, float* xbar, int N, int S, int E,
                     int nh, void* stream);

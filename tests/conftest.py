@@ -26,3 +26,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def parity_mode(request):
+    """The 1e-3 parity gates run twice: in the exact fp32-input MFMA mode (generic tile GEMMs, unfused attention) and in
+    the split-operand bf16x3 mode, which runs the token-on-lane Linear, fused attention and weight-gradient kernels on hi / lo
+    bf16 halves of the fp32 operands (GG_PREC_BF16X3).  gpu_util.engine_from_cfg builds its engines in the mode set here."""
+    import gpu_util
+    gpu_util.PARITY_PRECISION = request.param
+    yield request.param
+    gpu_util.PARITY_PRECISION = "f32"

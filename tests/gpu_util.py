@@ -132,8 +132,11 @@ class Checker:
         assert not self.bad, f"{self.tag}: " + ", ".join(f"{n} ({e:.2e})" for n, e in self.bad[:12])
 
 
-def engine_from_cfg(cfg, B, P, T, dropout=0.0, seed=0, optimizer=None):
-    return Engine(n_genes=cfg.n_genes, latent_dims=cfg.latent_dims, embedding_dims=cfg.embedding_dims,
+PARITY_PRECISION = "f32"      # set by the `parity_mode` fixture (tests/conftest.py): "f32" or "bf16x3"
+
+
+def engine_from_cfg(cfg, B, P, T, dropout=0.0, seed=0, optimizer=None, precision=None):
+    return Engine(precision=precision or PARITY_PRECISION, n_genes=cfg.n_genes, latent_dims=cfg.latent_dims, embedding_dims=cfg.embedding_dims,
                   hidden_dims=cfg.hidden_dims, text_dims=cfg.text_dims, patch_dims=cfg.patch_dims,
                   n_heads=cfg.n_heads, n_layers=cfg.n_layers, negative_slope=cfg.negative_slope, dropout=dropout,
                   lr_d=cfg.lr_d, lr_g=cfg.lr_g, optimizer=optimizer or cfg.optimizer, gp_weight=cfg.gp_weight,

@@ -9,7 +9,7 @@ from golden_util import FIXTURES, Golden, comparable
 from gemm_gan_amd import _lib as L
 from gpu_util import Checker, dev, engine_from_cfg
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("parity_mode")]      # every test in f32 AND in bf16x3 mode
 TOL = 1e-3
 
 

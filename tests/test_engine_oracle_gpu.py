@@ -80,6 +80,7 @@ def setup(case, seed=11):
     return cfg, tr, eng, batch
 
 
+@pytest.mark.usefixtures("parity_mode")
 @pytest.mark.parametrize("case", list(CASES))
 def test_critic_and_generator_iteration_vs_autograd(case):
     cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
@@ -110,6 +111,7 @@ def test_critic_and_generator_iteration_vs_autograd(case):
     ck.done()
 
 
+@pytest.mark.usefixtures("parity_mode")
 @pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256", "img_P40_E256"])
 def test_replica_stacked_passes_vs_autograd(case):
     """With dropout on, the three critic passes of an iteration run as replicas stacked on the batch axis (two of them

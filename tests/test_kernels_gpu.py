@@ -117,7 +117,7 @@ def run_linear(*, X, W, N, K, bias=None, y_bf16=False, x_bf16=False, relu=False,
         keep.append(t)
         return t
     Xd = dev(X, torch.bfloat16 if x_bf16 else torch.float32)
-    Wd = dev(W, torch.float32 if route == 2 else torch.bfloat16)
+    Wd = dev(W, torch.float32 if route >= 2 else torch.bfloat16)
     rows_out = M + (M // y_row_group if y_row_group else 0)
     ydt = torch.bfloat16 if y_bf16 else torch.float32
     if accumulate is not None:
@@ -140,8 +140,8 @@ def run_linear(*, X, W, N, K, bias=None, y_bf16=False, x_bf16=False, relu=False,
         a.drop_p, a.drop_seed, a.drop_site, a.drop_call = drop
         a.drop_ld = N
     if mask_ref is not None:
-        mr = dev(mask_ref, torch.float32 if route == 2 else torch.bfloat16)
-        a.mask_ref, a.ldref, a.mask_scale, a.mask_bf16 = mr.data_ptr(), N, mask_scale, int(route != 2)
+        mr = dev(mask_ref, torch.float32 if route >= 2 else torch.bfloat16)
+        a.mask_ref, a.ldref, a.mask_scale, a.mask_bf16 = mr.data_ptr(), N, mask_scale, int(route < 2)
     a.accumulate = int(accumulate is not None)
     if res is not None:
         rd = dev(res, torch.float32)
@@ -289,20 +289,23 @@ def test_token_on_lane_linear_kernels_equal_the_fp64_product(name):
     _linear_case(name, 1)
 
 
+@pytest.mark.parametrize("parts", [2, 3])
 @pytest.mark.parametrize("name", list(LINEAR_CASES))
-def test_split_operand_linear_equals_the_fp64_product_of_the_fp32_operands(name):
-    """Route 2 = tlin3_kernel (csrc/tlin3.hip), the Linear of the bf16x3 parity mode: the same calls with fp32 activations,
-    fp32 weights and fp32 outputs; hi / lo bf16 splits, three MFMAs per tile.  NO operand rounding in the reference: the bound
-    is the fp32 one (1e-4; measured ~5e-6), three orders below what one bf16 operand rounding costs."""
+def test_split_operand_linear_equals_the_fp64_product_of_the_fp32_operands(name, parts):
+    """Routes 2 / 3 = tlin3_kernel (csrc/tlin3.hip), the Linear of the bf16x3 parity mode: the same calls with fp32 activations,
+    fp32 weights and fp32 outputs.  NO operand rounding in the reference.  Two operand parts (hi, lo; three MFMAs per tile, the
+    backward form): measured 2 - 5e-6, bound 2e-5 - three orders below what one bf16 operand rounding costs.  Three parts (hi,
+    mid, lo; six MFMAs, the forward form, whose results decide ReLU gates): fp32-grade, bound 1e-6 (measured ~1e-7)."""
     build, _ = LINEAR_CASES[name]
     g = torch.Generator().manual_seed(abs(hash(name)) % 1000 + 77)
     kw = build(g)
     kw["W"] = kw["W"] + 1e-3 * rnd(g, *kw["W"].shape).double()          # fp32 weights that are NOT bf16-representable
     kw["X"] = kw["X"].float() + 1e-3 * rnd(g, *kw["X"].shape)
     kw.update(x_bf16=False, y_bf16=False)
-    got, cls = run_linear(**kw, route=2)
+    got, cls = run_linear(**kw, route=parts)
     want = ref_linear(**kw, exact=True)
-    diag(f"== Linear {name} (bf16x3, tlin3_kernel)")
+    diag(f"== Linear {name} (bf16x3, tlin3_kernel, {parts} operand parts)")
+    bl2, bmx = (2e-5, 4e-5) if parts == 2 else (1e-6, 2e-6)
     M = kw["X"].shape[0]
     yg = got["Y"].float().cpu()
     if kw.get("y_row_group"):
@@ -311,10 +314,10 @@ def test_split_operand_linear_equals_the_fp64_product_of_the_fp32_operands(name)
         yg = yg[rows]
     yr = kw["y_rows"] if kw.get("y_rows", -1) >= 0 else M
     assert yr == M or torch.isnan(yg[yr:]).all()
-    check("Y", yg[:yr], want["Y"][:yr], False)
+    check("Y", yg[:yr], want["Y"][:yr], False, bl2, bmx)
     if "ln_y" in want:
-        check("LayerNorm output", got["ln_y"], want["ln_y"], False)
-        check("LayerNorm statistics (mean, rstd)", got["ln_stats"].cpu()[:yr], want["ln_stats"][:yr], False)
+        check("LayerNorm output", got["ln_y"], want["ln_y"], False, bl2, bmx)
+        check("LayerNorm statistics (mean, rstd)", got["ln_stats"].cpu()[:yr], want["ln_stats"][:yr], False, bl2, bmx)
 
 
 # ---- fused self-attention ---------------------------------------------------------------------------------------------------
@@ -380,7 +383,7 @@ ATTN_SHAPES = [(257, 64), (258, 64), (1025, 64), (257, 16), (258, 16), (1025, 16
 
 
 @pytest.mark.parametrize("S,dh", ATTN_SHAPES)
-@pytest.mark.parametrize("io_bf16,pad,drop_on", [(1, True, True), (1, False, False), (0, True, True)])
+@pytest.mark.parametrize("io_bf16,pad,drop_on", [(1, True, True), (1, False, False), (0, True, True), (2, True, True), (3, True, True), (3, False, False)])
 def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf16, pad, drop_on):
     """attn_fwd_rm / attn_bwd_dq_rm / attn_bwd_dkv_rm (S <= 512: K, V resident in LDS) and attn_*_stream_kernel (S = 1025:
     BASELINE configs[4]) against float64 softmax attention on the stored operand values: S = 257 (one CLS row past eight tiles),
@@ -391,7 +394,8 @@ def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf
     N = 3 if S < 1000 else 2
     qkv, mask, dctx = attn_inputs(N, S, E, nh, seed=S + dh, pad=pad)
     drop = (0.1, 99, 2010, 5) if drop_on else None
-    dt = torch.bfloat16 if io_bf16 else torch.float32
+    x3 = io_bf16 >= 2                                        # split-operand kernels: fp32 tensors, io_bf16 = operand parts
+    dt = torch.bfloat16 if io_bf16 == 1 else torch.float32
     qkv_d, dctx_d = qkv.to(DEV, dt).contiguous(), dctx.to(DEV, dt).contiguous()
     mask_d = mask.to(DEV).view(torch.uint8).contiguous()
     ctx_d = torch.full((N, S, E), float("nan"), dtype=dt, device=DEV)
@@ -399,7 +403,9 @@ def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf
     dp = drop or (0.0, 0, 0, 0)
     names = [lib.gg_test_attn_kernel_name(w, S, E, nh).decode() for w in range(3)]
     diag(f"== attention S={S} dh={dh} io_bf16={io_bf16} pad={pad} dropout={drop_on}: {names}")
-    if dh == 64:        # the production head width: the kernels the bench times (cfg3: *_rm, configs[4]: *_stream)
+    if x3:
+        names = ["attn_fwd_x3_kernel", "attn_bwd_dq_x3_kernel", "attn_bwd_dkv_x3_kernel"]
+    elif dh == 64:      # the production head width: the kernels the bench times (cfg3: *_rm, configs[4]: *_stream)
         assert names[0] == ("attn_fwd_rm_kernel" if S < 1000 else "attn_fwd_stream_kernel")
         assert names[1] == ("attn_bwd_dq_rm_kernel" if S < 1000 else "attn_bwd_dq_stream_kernel")
         assert names[2] == ("attn_bwd_dkv_rm_kernel" if S < 1000 else "attn_bwd_dkv_stream_kernel")
@@ -411,16 +417,21 @@ def test_fused_attention_forward_and_backward_equal_the_fp64_result(S, dh, io_bf
                                  C.c_float(dp[0]), dp[1], dp[2], dp[3], io_bf16, 0, stream()))
     torch.cuda.synchronize()
     # the kernels convert fp32 operands to bf16 on load: the reference multiplies those values in both storage modes
-    want = ref_attention(bf(qkv_d.cpu()), mask, bf(dctx_d.cpu()), ctx_d.cpu().double(), nh, drop, dctx_stored=dctx_d.cpu().double())
-    bl2, bmx = (3.2e-3, 2.0 ** -7) if io_bf16 else (2.5e-3, 2.0 ** -7)
-    check("context", ctx_d, want["ctx"], True, bl2, bmx)
+    rd = (lambda t: t.float().double()) if x3 else bf       # split-operand kernels: NO operand rounding in the reference
+    want = ref_attention(rd(qkv_d.cpu()), mask, rd(dctx_d.cpu()), ctx_d.cpu().double(), nh, drop, dctx_stored=dctx_d.cpu().double())
+    bl2, bmx = (3.2e-3, 2.0 ** -7) if io_bf16 == 1 else (2.5e-3, 2.0 ** -7)
+    if io_bf16 == 2:
+        bl2, bmx = 4e-5, 2e-4           # two parts per operand: 2^-18 each (measured 3e-6 .. 2e-5, max-norm <= 1.1e-4)
+    if io_bf16 == 3:
+        bl2, bmx = 4e-6, 8e-6           # three parts: fp32 grade (measured 1e-7 .. 8e-7)
+    check("context", ctx_d, want["ctx"], io_bf16 == 1, bl2, bmx)
     valid = ~mask[:, None, :].expand(N, nh, S)
     check("log2-sum-exp", lse_d.cpu(), want["lse2"], False)
     dq, dk, dv = (dqkv_d[:, :, i * E:(i + 1) * E] for i in range(3))
     wq, wk, wv = (want["dqkv"][:, :, i * E:(i + 1) * E] for i in range(3))
-    check("dQ", dq, wq, True, bl2, bmx)
-    check("dK", dk, wk, True, bl2, bmx)
-    check("dV", dv, wv, True, bl2, bmx)
+    check("dQ", dq, wq, io_bf16 == 1, bl2, bmx)
+    check("dK", dk, wk, io_bf16 == 1, bl2, bmx)
+    check("dV", dv, wv, io_bf16 == 1, bl2, bmx)
     # masked keys receive exactly zero gradient
     mk = mask[:, :, None].expand(N, S, E)
     assert float(dk.float().cpu()[mk].abs().max() if mk.any() else 0.0) == 0.0
@@ -464,6 +475,13 @@ WGRAD_CASES = {
     "patch_encoder_film_on_the_fly": (16 * 256, 256, 1024, 0, 0, {"film": 256}),
     "film_gradient_contraction": (16 * 256, 256, 1024, 0, 0, {"fgrad": 256}),
     "narrow_panel_tail": (4096, 200, 328, 0, 0, {}),
+    # the split-operand (bf16x3) form of the parity mode: fp32 operands as hi / lo images, three MFMAs per tile - the reference
+    # is the float64 product of the UN-rounded fp32 values
+    "x3_ffn1_bias_ragged": (257 * 24, 512, 256, 0, 0, {"bias": True, "x3": 1}),
+    "x3_qkv_shared_rows": (3 * 2048, 768, 256, 0, 0, {"bias": True, "x_mod": 2048, "x3": 1}),
+    "x3_patch_encoder_film_on_the_fly": (16 * 256, 256, 1024, 0, 0, {"film": 256, "x3": 1}),
+    "x3_film_gradient_contraction": (16 * 256, 256, 1024, 0, 0, {"fgrad": 256, "x3": 1}),
+    "x3_narrow_panel_tail": (4096, 200, 328, 0, 0, {"x3": 1}),
 }
 
 
@@ -482,14 +500,16 @@ def test_weight_gradient_kernel_equals_the_fp64_reduction(name):
     dYd = dY.to(DEV, torch.bfloat16 if yb else torch.float32).contiguous()
     Xd = X.to(DEV, torch.bfloat16 if xb else torch.float32).contiguous()
     dWd = dW0.to(DEV).contiguous()
-    dyv, xv = bf(dYd.cpu()), bf(Xd.cpu())                   # the values the MFMAs see
+    x3 = ex.get("x3", 0)
+    rd = (lambda t: t.float().double()) if x3 else bf
+    dyv, xv = rd(dYd.cpu()), rd(Xd.cpu())                   # the values the MFMAs see
     film_g = film_b = fW = dgam = dbet = dbias = None
     rows = torch.arange(M) % x_rows
     if "film" in ex:
         grp = ex["film"]
         film_g, film_b = torch.tanh(rnd(g, M // grp, K)).to(DEV), rnd(g, M // grp, K).clamp(-5, 5).to(DEV)
         idx = torch.arange(M) // grp
-        xv = bf((film_g.cpu().double()[idx] * Xd.cpu().double() + film_b.cpu().double()[idx]).float())
+        xv = rd((film_g.cpu().double()[idx] * Xd.cpu().double() + film_b.cpu().double()[idx]).float())
     if "fgrad" in ex:
         grp = ex["fgrad"]
         fW = rnd(g, N, K, scale=0.05).to(DEV)
@@ -498,7 +518,7 @@ def test_weight_gradient_kernel_equals_the_fp64_reduction(name):
         dbias = torch.zeros(N, device=DEV)
     diag(f"== wgrad {name}: M={M} N={N} K={K} dY {'bf16' if yb else 'fp32'} X {'bf16' if xb else 'fp32'} {ex}")
     L.check(lib.gg_test_wgrad(P(dYd), N, yb, P(Xd), K, xb, P(dWd), K, M, N, K, P(film_g), P(film_b), K, ex.get("film", 0),
-                              P(fW), K, P(dgam), P(dbet), K, ex.get("fgrad", 0), P(dbias), ex.get("x_mod", 0), stream()))
+                              P(fW), K, P(dgam), P(dbet), K, ex.get("fgrad", 0), P(dbias), ex.get("x_mod", 0), x3, stream()))
     torch.cuda.synchronize()
     if "fgrad" in ex:
         grp = ex["fgrad"]
