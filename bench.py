@@ -323,20 +323,30 @@ def main():
                    for r in w.engine.gp_profile(B)]
     parity = None
     if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-        # the exact-fp32 path (f32-input MFMA, the mode the 1e-3 parity tests run in), same workload, 1 warm-up + N steps
-        w.engine.set_precision("f32")
-        train_once()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.parity_steps):
+        # The reference-precision figure: the SAME workload in the mode the 1e-3 parity gates run in.  bf16x3 = every fp32 operand
+        # as bf16 parts (three in forward products: six MFMAs per tile, fp32-grade; two in backward products: three MFMAs), fp32
+        # accumulate and fp32 storage, through the token-on-lane Linear, fused attention and weight-gradient kernels; f32 = the exact
+        # fp32-input MFMA on the generic tile GEMMs with unfused attention (the round-1 / round-2 parity mode), timed beside it.
+        def timed(mode, steps):
+            w.engine.set_precision(mode)
             train_once()
-        torch.cuda.synchronize(dev)
-        pdt = (time.perf_counter() - t1) / args.parity_steps
-        parity = {"dtype": "f32", "ms_per_step": round(pdt * 1e3, 3), "value": round(B / pdt, 2), "unit": "samples/s",
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                train_once()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t1) / steps
+        pdt = timed("bf16x3", args.parity_steps)
+        fdt = timed("f32", max(2, args.parity_steps // 2))
+        parity = {"dtype": "bf16x3", "ms_per_step": round(pdt * 1e3, 3), "value": round(B / pdt, 2), "unit": "samples/s",
                   "steps": args.parity_steps,
-                  "note": "THE REFERENCE-PRECISION FIGURE: exact fp32-input MFMA path, the mode held to <= 1e-3 elementwise against "
-                          "the reference (tests/test_engine_golden_gpu.py); the headline `value` is the bf16-operand mode "
-                          "north_star prescribes, whose measured error bounds are in tests/test_bf16_parity_gpu.py"}
+                  "f32_mode": {"dtype": "f32", "ms_per_step": round(fdt * 1e3, 3), "value": round(B / fdt, 2), "steps": max(2, args.parity_steps // 2)},
+                  "note": "THE REFERENCE-PRECISION FIGURE: split-operand bf16x3 mode (fp32 operands as bf16 parts, fp32 accumulate, fp32 "
+                          "storage) through the fused kernels - the mode tests/test_engine_golden_gpu.py and tests/test_engine_oracle_gpu.py "
+                          "hold to <= 1e-3 elementwise against the reference (every test also runs in f32_mode, the exact fp32-input MFMA "
+                          "path on the generic kernels); the headline `value` is the bf16-operand mode north_star prescribes, whose kernels "
+                          "are held to float64 results on rounded operands in tests/test_kernels_gpu.py and whose gradient error is shown to "
+                          "be ReLU gate flips in tests/test_gate_flips_gpu.py"}
         w.engine.set_precision("bf16")
     finite = bool(torch.isfinite(w.engine.flat[0]["w"]).all() and torch.isfinite(w.engine.flat[1]["w"]).all())
 

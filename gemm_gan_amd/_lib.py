@@ -44,7 +44,7 @@ class GGTestLinear(C.Structure):       # gg_test_linear_args (include/gemmgan.h)
                 ("accumulate", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("res_rows", C.c_int64),
                 ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p),
-                ("route", C.c_int32)]
+                ("w_parts", C.c_void_p), ("route", C.c_int32)]
 
 
 class GGCond(C.Structure):

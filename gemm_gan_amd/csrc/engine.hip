@@ -47,7 +47,7 @@ struct Net {
     // bf16 shadow copies of the 2-D conditioning-stack weights (same offsets as the flat fp32 buffer):
     // wb = W [rows][cols], wtb = W^T [cols][rows]; refreshed from the fp32 master at every public entry
     char *wb = nullptr, *wtb = nullptr;
-    float* wt32 = nullptr;     // bf16x3 mode: fp32 W^T, same offsets
+    char *wp3 = nullptr, *wtp3 = nullptr;     // bf16x3 mode: three bf16 parts (hi, mid, lo) of W / W^T, part sp at + 2 * total * sp bytes
     // fp8 mode: e4m3 shadow of the same weights (tensor at byte offset 2 * flat offset), per-tensor exponents
     char* w8 = nullptr;
     unsigned* w8_amax = nullptr;
@@ -397,7 +397,8 @@ size_t carve(gg_engine* e, void* base) {
         Net& n = e->net[r];
         n.wb = a.take<char>((size_t)n.total * 2);
         n.wtb = a.take<char>((size_t)n.total * 2);
-        n.wt32 = a.take<float>((size_t)n.total);
+        n.wp3 = a.take<char>((size_t)n.total * 2 * 3);
+        n.wtp3 = a.take<char>((size_t)n.total * 2 * 3);
         n.tab_dev = a.take<ShadowEntry>(n.tab.size() + 1);
         n.w8 = a.take<char>((size_t)n.total * 2);
         n.w8_amax = a.take<unsigned>(n.tab.size() + 1);
@@ -623,8 +624,8 @@ inline bool use_tlin(gg_engine* e) { return e->tlin_on && e->precision == GG_PRE
 
 int refresh_shadows(Ctx& c, Net& n) {
     if (!use_tlin(c.e) || n.tab.empty()) return 0;
-    if (c.e->x3) {          // the split-operand Linears read the fp32 master weights; only W^T has to be made
-        KL(k_shadow_weights_t32(n.w, n.wt32, n.tab_dev, (int)n.tab.size(), c.st));
+    if (c.e->x3) {          // the split-operand Linears read pre-split bf16 parts of W and W^T
+        KL(k_shadow_parts(n.w, n.wp3, n.wtp3, n.total, n.tab_dev, (int)n.tab.size(), c.st));
         return 0;
     }
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
@@ -652,14 +653,14 @@ inline const void* WTB(const Net& n, long off) { return n.wtb + 2 * off; }    //
 
 // launches the token-on-lane kernel when enabled and the shape qualifies; returns 1 if it ran
 // bf16x3: the call sites hand over bf16 shadow weights (W or W^T at the flat offset of the tensor); the split-operand kernel reads
-// the fp32 master copy / its fp32 transpose at the same offset
+// the three-part shadow of the same orientation at the same offset
 // returns the number of operand parts: 3 (six products, fp32-grade) for a forward Linear (W: its results decide ReLU gates), 2 (three
 // products) for a backward one (W^T); 0: not a shadow pointer
 int x3_weights(gg_engine* e, TlinP& t) {
     const char* w = reinterpret_cast<const char*>(t.W);
     for (Net& n : e->net) {
-        if (n.wb && w >= n.wb && w < n.wb + 2 * (size_t)n.total) { t.W = n.w + (w - n.wb) / 2; return 3; }
-        if (n.wtb && w >= n.wtb && w < n.wtb + 2 * (size_t)n.total) { t.W = n.wt32 + (w - n.wtb) / 2; return 2; }
+        if (n.wb && w >= n.wb && w < n.wb + 2 * (size_t)n.total) { t.W = n.wp3 + (w - n.wb); t.w_part_stride = n.total; return 3; }
+        if (n.wtb && w >= n.wtb && w < n.wtb + 2 * (size_t)n.total) { t.W = n.wtp3 + (w - n.wtb); t.w_part_stride = n.total; return 2; }
     }
     return 0;
 }

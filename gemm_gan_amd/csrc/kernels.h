@@ -160,6 +160,7 @@ int flash_attn_bwd_x3(const float* qkv, const float* ctx, const float* dctx, con
 struct TlinP {
     const void* X = nullptr; long ldx = 0; long M = 0; int x_bf16 = 0;       // activations fp32 or bf16 (row stride in elements)
     const void* W = nullptr; long ldw = 0;          // bf16 [N][K] (row stride ldw elements)
+    long w_part_stride = 0;                         // tlin3 only: W is the first of NS bf16 part images, this many elements apart
     const float* bias = nullptr;
     void* Y = nullptr; long ldy = 0; int y_bf16 = 0;                          // output fp32 or (stream mode only) bf16
     long y_rows = -1;                               // resident + LayerNorm: Y (pre-LN sum) is stored for tokens < y_rows only (-1: all);
@@ -204,6 +205,11 @@ struct ShadowEntry { long off; int rows, cols; };
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 // bf16x3 mode: wt = W^T [cols][rows] in fp32 at the same offsets
 int k_shadow_weights_t32(const float* w, float* wt, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
+// bf16x3 mode: the three bf16 parts (hi, mid, lo) of every shadowed weight in both orientations: wp[sp * part_stride + off ..] = part sp
+// of W [rows][cols], wtp likewise of W^T [cols][rows]
+int k_shadow_parts(const float* w, void* wp, void* wtp, long part_stride, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
+// parts[sp * part_stride + i] = part sp of w[i], i < n (tests)
+int k_split_weights(const float* w, void* parts, long n, long part_stride, int nparts, hipStream_t st);
 // e4m3 shadow: w8[2*off + i] = e4m3(w[off + i] * 2^w_exp[entry]), w_exp[entry] = floor(log2(448 / max|w|)); amax: scratch [n_entries]
 int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "drop_rng.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
 
 namespace gg {
 namespace {
@@ -32,8 +33,8 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr float LN_EPS = 1e-5f;
-// K slice per pass: 128 with two operand parts, 64 with three (the same 24 MFMAs per 32-feature chunk, half the fragment registers)
-template <int NS> struct Slice { static constexpr int KSL = NS == 3 ? 64 : 128, WLD = KSL + 8; };
+// K slice per pass: 64 (12 / 24 MFMAs per 32-feature chunk with two / three operand parts); the next slice's activations are in flight meanwhile
+template <int NS> struct Slice { static constexpr int KSL = 64, WLD = KSL + 8; };
 
 // v -> (hi, lo) pairs of two values, packed as bf16x2 words
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -64,63 +65,61 @@ __device__ __forceinline__ void splitn(const f32x4 v, u32x2 (&out)[NS]) {
     }
 }
 
-// rows [tok0, tok0 + 32) x [k0, k0 + KSL) of X (fp32, FiLM optional) as hi / lo bf16 images into the wave-private slabs
+// rows [tok0, tok0 + 32) x [k0, k0 + KSL) of X (fp32, FiLM optional) on their way into the wave-private slabs as NS bf16 images:
+// request() issues every load of the slice into registers, commit() (one K slice of MFMAs later: the loads have landed, nothing
+// waits on HBM) modulates, splits and writes them to LDS.  Without the split into two phases each slice exposed a full memory
+// round trip at one wave per SIMD (the tile loop ran at 23 % of the MFMA rate).
 template <int NS>
-__device__ __forceinline__ void stage_x3(const TlinP& p, __bf16* xs, int tok0, int last_tok, int k0, int lane) {   // xs: NS images, 4 * 32 * WLD apart
-    constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
-    asm volatile("" : "+v"(tok0));
-    const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
-    constexpr int LPR = KSL / 4, RPI = 64 / LPR, NLD = 32 / RPI, GB = NLD < 8 ? NLD : 8;      // KSL 128: 2 rows per instruction, 16 loads in two batches
-    const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
-    const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
-    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, ba = {0.f, 0.f, 0.f, 0.f}, gb = ga, bb = ba;
-    int tb = 0, rem0 = 0;
-    if (p.film_g) {         // FiLM rows are per sample (film_group >= 32 tokens): a 32-token tile touches at most two of them
-        tb = min(tok0, last_tok);
-        const int g0 = tb / p.film_group;
-        rem0 = tb - g0 * p.film_group;
-        const int g1 = min(g0 + 1, last_tok / p.film_group);
-        const unsigned fldb = (unsigned)p.film_ld * 4u;
-        const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g) + cb;
-        const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b) + cb;
-        ga = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g0 * fldb); ba = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g0 * fldb);
-        gb = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g1 * fldb); bb = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g1 * fldb);
-    }
-    f32x4 v[2][GB];
-#pragma unroll
-    for (int i = 0; i < GB; ++i) v[0][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
-#pragma unroll
-    for (int b0 = 0; b0 < NLD; b0 += GB) {
-        const int cur = (b0 / GB) & 1;
-        if (b0 + GB < NLD) {
-#pragma unroll
-            for (int i = 0; i < GB; ++i)
-                v[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * (b0 + GB + i), last_tok) * ldb + cb));
+struct XStage {
+    static constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
+    static constexpr int LPR = KSL / 4, RPI = 64 / LPR, NLD = 32 / RPI;
+    f32x4 v[NLD];
+    f32x4 ga, ba, gb, bb;
+    int tb, rem0;
+    __device__ __forceinline__ void request(const TlinP& p, int tok0, int last_tok, int k0, int lane) {
+        asm volatile("" : "+v"(tok0));
+        const unsigned char* const Xc = reinterpret_cast<const unsigned char*>(p.X);
+        const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
+        const unsigned ldb = (unsigned)p.ldx * 4u, cb = (unsigned)(k0 + lcol) * 4u;
+        if (p.film_g) {         // FiLM rows are per sample (film_group >= 32 tokens): a 32-token tile touches at most two of them
+            tb = min(tok0, last_tok);
+            const int g0 = tb / p.film_group;
+            rem0 = tb - g0 * p.film_group;
+            const int g1 = min(g0 + 1, last_tok / p.film_group);
+            const unsigned fldb = (unsigned)p.film_ld * 4u;
+            const unsigned char* const Gc = reinterpret_cast<const unsigned char*>(p.film_g) + cb;
+            const unsigned char* const Bc = reinterpret_cast<const unsigned char*>(p.film_b) + cb;
+            ga = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g0 * fldb); ba = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g0 * fldb);
+            gb = *reinterpret_cast<const f32x4*>(Gc + (unsigned)g1 * fldb); bb = *reinterpret_cast<const f32x4*>(Bc + (unsigned)g1 * fldb);
         }
 #pragma unroll
-        for (int i = 0; i < GB; ++i) {
-            f32x4 m = v[cur][i];
+        for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const f32x4*>(Xc + ((unsigned)min(tok0 + lrow + RPI * i, last_tok) * ldb + cb));
+    }
+    __device__ __forceinline__ void commit(const TlinP& p, __bf16* xs, int tok0, int last_tok, int lane) const {     // xs: NS images, 4 * 32 * WLD apart
+        const int lrow = lane / LPR, lcol = 4 * (lane % LPR);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            f32x4 m = v[i];
             if (p.film_g) {
-                const int r = min(tok0 + lrow + RPI * (b0 + i), last_tok);
+                const int r = min(tok0 + lrow + RPI * i, last_tok);
                 const bool second = rem0 + (r - tb) >= p.film_group;
                 m = (second ? gb : ga) * m + (second ? bb : ba);
             }
             u32x2 parts[NS];
             splitn<NS>(m, parts);
-            const int o = (RPI * (b0 + i) + lrow) * WLD + lcol;
+            const int o = (RPI * i + lrow) * WLD + lcol;
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x2*>(&xs[sp * (4 * 32 * WLD) + o]) = parts[sp];
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
-}
+};
 
 template <int NT_RES, int NS>
 __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
     constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
     constexpr int N = 32 * NT_RES;                     // columns of this workgroup's group
-    constexpr int WLOADS = 32 * (KSL / 4) / 256;       // float4 pieces per thread and weight chunk (4)
+    static_assert(KSL == 64, "weight chunk staging: 32 rows x 8 pieces = 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int WIMG = 2 * 32 * WLD, XIMG = 4 * 32 * WLD;                 // elements per weight / activation image (one split part)
     __bf16* const Wsp = reinterpret_cast<__bf16*>(smem_raw);                // [NS][2][32*WLD]
@@ -136,29 +135,25 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const int nchunks = nks * NT_RES;
     __bf16* const xs = Xsp + wave * 32 * WLD;          // this wave's slab of part 0; part sp at + sp * XIMG
 
-    // weight chunks (32 output features x KSL, fp32) travel L2 -> registers -> (split) -> LDS two chunks ahead of their use
-    f32x4 wreg[2][WLOADS];
-    const float* Wp = reinterpret_cast<const float*>(p.W);
+    // weight chunks (32 output features x KSL) travel L2 -> registers -> LDS two chunks ahead of their use.  The weights arrive
+    // PRE-SPLIT: NS bf16 images [N][K], w_part_stride elements apart (k_split_weights; the engine refreshes them with the other
+    // shadow copies) - splitting fp32 weights here cost ~70 VALU instructions per thread and chunk, outside the MFMA shadow at
+    // one wave per SIMD
+    u32x4 wreg[2][NS];
+    const __bf16* Wp = reinterpret_cast<const __bf16*>(p.W);
+    const int wrow = tid >> 3, wpiece = tid & 7;        // 32 rows x 8 pieces of 8 bf16
     auto load_chunk = [&](int set, int ks, int nt) {
+        const __bf16* src = Wp + (long)(gcol + nt * 32 + wrow) * p.ldw + ks * KSL + 8 * wpiece;
 #pragma unroll
-        for (int i = 0; i < WLOADS; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f / (KSL / 4), piece = f % (KSL / 4);
-            wreg[set][i] = *reinterpret_cast<const f32x4*>(Wp + (long)(gcol + nt * 32 + row) * p.ldw + ks * KSL + 4 * piece);
-        }
+        for (int sp = 0; sp < NS; ++sp) wreg[set][sp] = *reinterpret_cast<const u32x4*>(src + (long)sp * p.w_part_stride);
     };
     auto store_chunk = [&](int set) {
 #pragma unroll
-        for (int i = 0; i < WLOADS; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f / (KSL / 4), piece = f % (KSL / 4);
-            u32x2 parts[NS];
-            splitn<NS>(wreg[set][i], parts);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x2*>(&Wsp[sp * WIMG + set * 32 * WLD + row * WLD + 4 * piece]) = parts[sp];
-        }
+        for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x4*>(&Wsp[sp * WIMG + set * 32 * WLD + wrow * WLD + 8 * wpiece]) = wreg[set][sp];
     };
 
+    XStage<NS> xst;
+    xst.request(p, tok0, last_tok, 0, lane);
     load_chunk(0, 0, 0);
     load_chunk(1, 0, 1);
     for (int i = tid; i < N; i += 256) {
@@ -197,7 +192,8 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
-        stage_x3<NS>(p, xs, tok0, last_tok, ks * KSL, lane);
+        xst.commit(p, xs, tok0, last_tok, lane);
+        if (ks + 1 < nks) xst.request(p, tok0, last_tok, (ks + 1) * KSL, lane);
         if (ks == nks - 1) load_pre(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -218,20 +214,26 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             }
             const __bf16* wb0 = Wsp + buf * 32 * WLD + c * WLD + 8 * h;
+            // the fragments of k-step s + 1 are requested before the MFMAs of k-step s: one exposed LDS round trip per chunk, not per step
+            bf16x8 wf[2][NS];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) wf[0][sp] = *reinterpret_cast<const bf16x8*>(wb0 + sp * WIMG);
 #pragma unroll
             for (int s = 0; s < KSL / 16; ++s) {
-                bf16x8 wf[NS];
+                if (s + 1 < KSL / 16) {
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) wf[sp] = *reinterpret_cast<const bf16x8*>(wb0 + sp * WIMG + 16 * s);
+                    for (int sp = 0; sp < NS; ++sp) wf[(s + 1) & 1][sp] = *reinterpret_cast<const bf16x8*>(wb0 + sp * WIMG + 16 * (s + 1));
+                }
+                const bf16x8(&w)[NS] = wf[s & 1];
                 // small terms first, the leading product last
                 if constexpr (NS == 3) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[0][s], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2][s], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[1][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], xf[0][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[2][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], xf[1][s], acc[nt], 0, 0, 0);
                 }
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[0][s], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1][s], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], xf[0][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[1][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[0][s], acc[nt], 0, 0, 0);
             }
             if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
             __syncthreads();
@@ -340,14 +342,15 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 void tlin3_time_next(hipEvent_t begin, hipEvent_t end) { g3_ev0 = begin; g3_ev1 = end; }
 
-// fp32 X / W / Y (and fp32 gate reference); N a multiple of 32 up to 256, or a multiple of 256 (column groups); K a multiple of 128
+// fp32 X / Y (and fp32 gate reference), W as pre-split bf16 part images (k_split_weights: p.W = part 0 [N][K], part sp at + sp * p.w_part_stride
+// elements); N a multiple of 32 up to 256, or a multiple of 256 (column groups); K a multiple of 128
 bool tlin3_supported(const TlinP& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (double)p.M * (double)p.ldx * 4.0 >= 4.0e9) return false;      // 32-bit row offsets
     if (p.x_bf16 || p.y_bf16 || p.fp8 || (p.mask_ref && p.mask_bf16)) return false;
     if (p.K % 128) return false;
     if (!(p.N == 64 || p.N == 128 || p.N == 256 || (p.N > 256 && p.N % 256 == 0))) return false;
     if (p.ln_g && (p.N > 256 || !p.ln_b || !p.ln_y || !p.ln_stats || !al16(p.ln_y))) return false;
-    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % 4 || p.ldy % 4 || p.ldw % 4) return false;
+    if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % 4 || p.ldy % 4 || p.ldw % 8 || p.w_part_stride % 8 || p.w_part_stride <= 0) return false;
     if (p.film_g && (!al16(p.film_g) || !al16(p.film_b) || p.film_ld % 4 || p.film_group < 32)) return false;
     if (p.mask_ref && (!al16(p.mask_ref) || p.ldref % 4)) return false;
     if (p.res && (!al16(p.res) || p.ldres % 4 || p.res_rows < 1)) return false;
@@ -366,6 +369,75 @@ int tlin3(const TlinP& p, hipStream_t st, int nsplit) {
     if (p.N == 64) return launch3<2, 2>(p, 1, st);
     if (p.N == 128) return launch3<4, 2>(p, 1, st);
     return launch3<8, 2>(p, p.N / 256, st);
+}
+
+namespace {
+// parts[sp][i] = sp-th bf16 part of w[i] (hi, then the bf16 roundings of the successive remainders); optionally the same for the
+// transpose of every 2-D tensor of a shadow table (tab == nullptr: one flat array of n elements, no transpose)
+__global__ void split_flat_kernel(const float* __restrict__ w, __bf16* __restrict__ parts, long n, long part_stride, int nparts) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = w[i];
+        for (int sp = 0; sp < nparts; ++sp) {
+            const __bf16 b = (__bf16)r;
+            parts[sp * part_stride + i] = b;
+            r -= (float)b;
+        }
+    }
+}
+__global__ void split_tab_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, __bf16* __restrict__ wtp, long part_stride,
+                                 const ShadowEntry* __restrict__ tab) {
+    __shared__ float t[32][33];
+    const ShadowEntry e = tab[blockIdx.y];
+    const int tiles_c = (e.cols + 31) / 32, ntile = ((e.rows + 31) / 32) * tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            const bool in = r < e.rows && c < e.cols;
+            float v = in ? w[e.off + (long)r * e.cols + c] : 0.f;
+            t[ty + 8 * k][tx] = v;
+            if (in) {
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const __bf16 b = (__bf16)v;
+                    wp[sp * part_stride + e.off + (long)r * e.cols + c] = b;
+                    v -= (float)b;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < e.rows && c < e.cols) {
+                float v = t[tx][ty + 8 * k];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const __bf16 b = (__bf16)v;
+                    wtp[sp * part_stride + e.off + (long)c * e.rows + r] = b;
+                    v -= (float)b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+int k_split_weights(const float* w, void* parts, long n, long part_stride, int nparts, hipStream_t st) {
+    if (n <= 0) return 0;
+    const long blocks = std::min<long>((n + 255) / 256, 2048);
+    split_flat_kernel<<<(unsigned)blocks, 256, 0, st>>>(w, reinterpret_cast<__bf16*>(parts), n, part_stride, nparts);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int k_shadow_parts(const float* w, void* wp, void* wtp, long part_stride, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {
+    if (n_entries <= 0) return 0;
+    split_tab_kernel<<<dim3(64, n_entries), 256, 0, st>>>(w, reinterpret_cast<__bf16*>(wp), reinterpret_cast<__bf16*>(wtp), part_stride, tab_dev);
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // namespace gg

@@ -238,6 +238,7 @@ typedef struct gg_test_linear_args {     /* Y = epi(X W^T): the encoder-layer Li
     int32_t accumulate;                                          /* y += previous content                                      */
     const float* res; int64_t ldres; int64_t res_rows;           /* + res[row % res_rows]                                      */
     const float* ln_g; const float* ln_b; float* ln_y; float* ln_stats;                  /* LayerNorm of the sum (eps 1e-5)    */
+    void* w_parts;     /* routes 2 / 3: scratch for the pre-split weights, route * N * K bf16 elements                                  */
     int32_t route;     /* 0: as the engine routes it (weight-stationary kernel when one takes the shape), 1: token-on-lane kernels only,
                           2 / 3: the split-operand Linear of GG_PREC_BF16X3 with 2 (hi, lo: three products, the backward form) /
                           3 (hi, mid, lo: six products, the forward form) operand parts; W is then the fp32 matrix                  */

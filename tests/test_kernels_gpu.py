@@ -154,6 +154,10 @@ def run_linear(*, X, W, N, K, bias=None, y_bf16=False, x_bf16=False, relu=False,
         out["ln_stats"] = torch.full((M, 2), float("nan"), device=DEV)
         a.ln_g, a.ln_b, a.ln_y, a.ln_stats = gd.data_ptr(), bd.data_ptr(), out["ln_y"].data_ptr(), out["ln_stats"].data_ptr()
     a.route = route
+    if route >= 2:
+        wparts = torch.empty(route * N * K, dtype=torch.bfloat16, device=DEV)
+        keep.append(wparts)
+        a.w_parts = wparts.data_ptr()
     cls = C.c_int32(-1)
     L.check(lib.gg_test_linear(C.byref(a), C.byref(cls), stream()))
     torch.cuda.synchronize()
