@@ -166,6 +166,7 @@ struct gg_engine {
     float *dA, *dB;            // [3B, H] scratch
     float *dc;                 // [3B, E]
     float *gp_g2, *gp_g1, *gp_g1s, *gp_grad, *gp_nrm2, *gp_coef, *gp_dg1, *gp_dg2;
+    float* gp_nrm2p = nullptr; // [gp_grad3_parts(G)][B] per-strip partial row norms of the split-operand gradient kernel
     float *dxfake;             // [B, G]
     float *sumsq;              // [4]
     // conditioning backward scratch
@@ -418,6 +419,7 @@ size_t carve(gg_engine* e, void* base) {
     e->dc = a.take<float>(3 * B * E);
     e->gp_g2 = a.take<float>(B * H); e->gp_g1 = a.take<float>(B * H); e->gp_g1s = a.take<float>(B * H);
     e->gp_grad = a.take<float>(B * G); e->gp_nrm2 = a.take<float>(B); e->gp_coef = a.take<float>(B);
+    e->gp_nrm2p = a.take<float>((long)gp_grad3_parts((int)G) * B);
     e->gp_dg1 = a.take<float>(B * H); e->gp_dg2 = a.take<float>(B * H);
     e->dxfake = a.take<float>(B * G);
     e->sumsq = a.take<float>(2 * 1024 + 8);
@@ -1527,9 +1529,11 @@ int gp_chain(Ctx& c, Net& D, const float* a1h, const float* a2h, int B, float* g
     const int G = e->G, E = e->E, H = e->H;
     const float slope = e->cfg.negative_slope;
     KL(k_gp_front(a1h, a2h, D.w + D.w3, D.w + D.w2, e->gp_g1, e->gp_dg1, e->gp_nrm2, B, H, slope, c.st));   // g1 = m1 * ((m2*w3) W2)
-    KL(k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, c.st));                       // grad = g1 W1x, |grad|^2
-    KL(k_gp_coef_scale(e->gp_nrm2, e->gp_g1, e->gp_coef, backward ? e->gp_g1s : nullptr, gp_loss, B, H,
-                       e->cfg.gp_weight, c.st));
+    const bool g3 = gp_grad3_ok(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, B, H, G);
+    if (g3) KL(k_gp_grad3(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2p, B, H, G, c.st));             // grad = g1 W1x, |grad|^2 per strip
+    else KL(k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, c.st));
+    KL(k_gp_coef_scale(g3 ? e->gp_nrm2p : e->gp_nrm2, e->gp_g1, e->gp_coef, backward ? e->gp_g1s : nullptr, gp_loss, B, H,
+                       e->cfg.gp_weight, c.st, g3 ? gp_grad3_parts(G) : 1, e->gp_nrm2));
     if (!backward) return 0;
     {
         Ctx cs = c;
@@ -1984,8 +1988,11 @@ int gg_gp_profile(gg_engine* e, int B, int reps, double* us, double* bytes, void
             gp_time_next(ev[0], ev[1]);
             int rc = 0;
             if (k == 0) rc = k_gp_front(a1h, a2h, D.w + D.w3, D.w + D.w2, e->gp_g1, e->gp_dg1, e->gp_nrm2, B, H, slope, st);
-            if (k == 1) rc = k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, st);
-            if (k == 2) rc = k_gp_coef_scale(e->gp_nrm2, e->gp_g1, e->gp_coef, e->gp_g1s, e->sumsq + 2048, B, H, e->cfg.gp_weight, st);
+            const bool g3 = gp_grad3_ok(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, B, H, G);
+            if (k == 1) rc = g3 ? k_gp_grad3(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2p, B, H, G, st)
+                                : k_gp_grad(e->gp_g1, D.w + D.w1, G + E, e->gp_grad, e->gp_nrm2, B, H, G, st);
+            if (k == 2) rc = k_gp_coef_scale(g3 ? e->gp_nrm2p : e->gp_nrm2, e->gp_g1, e->gp_coef, e->gp_g1s, e->sumsq + 2048, B, H, e->cfg.gp_weight, st,
+                                             g3 ? gp_grad3_parts(G) : 1, e->gp_nrm2);
             if (k == 3) rc = k_gp_tail(e->gp_dg1, e->gp_coef, a1h, a2h, D.w + D.w3, D.w + D.w2, D.g + D.w2, D.g + D.w3, B, H, slope, st);
             if (rc != 0) return rc;
             GG_CHECK_HIP(hipEventSynchronize(ev[1]));

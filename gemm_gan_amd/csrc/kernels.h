@@ -124,9 +124,14 @@ int k_gp_front(const float* a1, const float* a2, const float* w3, const float* W
                int H, float slope, hipStream_t st);
 // grad [B,G] = g1 [B,H] W1x, W1x[k,g] = W1[k*ldw + g]; nrm2[b] += sum_g grad[b,g]^2 in the epilogue
 int k_gp_grad(const float* g1, const float* W1, long ldw, float* grad, float* nrm2, int B, int H, int G, hipStream_t st);
-// coef[b] = gp_weight*(2/B)*(nrm-1)/nrm ; *loss += mean((nrm-1)^2) ; g1s = coef * g1 (g1s may be null)
+// the same product on the split-operand strip kernel (round 3): 32 genes x up to 256 rows per workgroup, six bf16 part products per tile
+// (fp32-grade), nrm2p [gp_grad3_parts(G)][B] = per-strip partial sums of squares (no atomics; k_gp_coef_scale adds them in order)
+int gp_grad3_parts(int G);
+bool gp_grad3_ok(const float* g1, const float* W1, long ldw, const float* grad, int B, int H, int G);
+int k_gp_grad3(const float* g1, const float* W1, long ldw, float* grad, float* nrm2p, int B, int H, int G, hipStream_t st);
+// coef[b] = gp_weight*(2/B)*(nrm-1)/nrm ; *loss += mean((nrm-1)^2) ; g1s = coef * g1 (g1s may be null); nparts > 1: nrm2 = [nparts][B] partials
 int k_gp_coef_scale(const float* nrm2, const float* g1, float* coef, float* g1s, float* loss, int B, int H, float gp_weight,
-                    hipStream_t st);
+                    hipStream_t st, int nparts = 1, float* nrm2_total = nullptr);      // nrm2_total [B] (optional): the summed squares
 // du = m1 * coef * dg1pre ; dW2 += (m2*w3)^T du ; dw3 += sum_b m2 * (du W2^T)   (atomic adds)
 int k_gp_tail(const float* dg1pre, const float* coef, const float* a1, const float* a2, const float* w3, const float* W2, float* dW2,
               float* dw3, int B, int H, float slope, hipStream_t st);
