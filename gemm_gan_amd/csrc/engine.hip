@@ -502,6 +502,11 @@ int run_gemm(Ctx& c, const GemmP& p) {
     e->launches++;
     // bf16x3: the few-tile products (MLP heads, cross-attention projections, FiLM head) run on the exact fp32-input MFMA
     const bool bf16 = e->precision == GG_PREC_BF16 && !e->x3;
+    if (e->x3 && e->precision == GG_PREC_BF16 && e->small_on && gemm_small_wanted(p) && gemm_small_x3_ok(p)) {
+        ProfScope ps(c, "gemm_tiny_kernel<x3>", 6.0 * 2.0 * p.M * p.N * (double)p.K * p.batch,
+                     4.0 * p.batch * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N));
+        return gemm_small_x3(p, c.st);
+    }
     const bool small = bf16 && e->small_on && gemm_small_wanted(p);
     static const char* small_names[4] = {"gemm_small_kernel<0,0>", "gemm_small_kernel<0,1>", "gemm_small_kernel<1,0>", "gemm_small_kernel<1,1>"};
     const int cls_ = !e->prof_on ? 0 : small ? named_class(e, small_names[p.layA * 2 + p.layB]) : p.layA * 2 + p.layB + (bf16 ? 4 : 0);

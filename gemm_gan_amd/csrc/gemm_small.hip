@@ -210,9 +210,33 @@ struct FragLoader {
         const u32x4 w = {pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7])};
         return __builtin_bit_cast(bf16x8, w);
     }
+    // the fragment as NS bf16 parts (hi, then the roundings of the successive remainders): the split-operand form of GG_PREC_BF16X3
+    template <int NS>
+    __device__ __forceinline__ void get_parts(int s, bool valid, bf16x8 (&out)[NS]) const {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = valid ? x[s][j] : 0.f;
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            __bf16 b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (__bf16)y[j];
+            const bf16x2_t w0 = {b[0], b[1]}, w1 = {b[2], b[3]}, w2 = {b[4], b[5]}, w3 = {b[6], b[7]};
+            const u32x4 w = {__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1), __builtin_bit_cast(unsigned, w2),
+                             __builtin_bit_cast(unsigned, w3)};
+            out[sp] = __builtin_bit_cast(bf16x8, w);
+            if (sp + 1 < NS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] -= (float)b[j];
+            }
+        }
+    }
 };
 
-template <int LA, int LB>
+// NS = 1: bf16 operands.  NS = 3: both operands as three bf16 parts, six part products per step, fp32 accumulate - fp32-grade results
+// for the few-tile products of the bf16x3 parity mode (MLP heads, cross-attention projections), which otherwise run on the
+// 128 x 128 fp32-input tile kernel at ~50 us per launch
+template <int LA, int LB, int NS = 1>
 __global__ __launch_bounds__(NT) void gemm_tiny_kernel(const GemmP p, int kchunk) {
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -252,7 +276,19 @@ __global__ __launch_bounds__(NT) void gemm_tiny_kernel(const GemmP p, int kchunk
 #pragma unroll
                 for (int s = 0; s < TG; ++s) {
                     const bool valid = kw0 + 16 * TG * g + 16 * s + 8 * h < kw1;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u].get(s, valid), fb[u].get(s, valid), acc, 0, 0, 0);
+                    if constexpr (NS == 1) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u].get(s, valid), fb[u].get(s, valid), acc, 0, 0, 0);
+                    } else {
+                        bf16x8 a3[NS], b3[NS];
+                        fa[u].template get_parts<NS>(s, valid, a3);
+                        fb[u].template get_parts<NS>(s, valid, b3);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -300,6 +336,38 @@ int launch(const GemmP& p, int vecA, int vecB, int kchunk, dim3 grid, hipStream_
     return 0;
 }
 }  // namespace
+
+namespace {
+bool tiny_ok(const GemmP& p) {
+    const bool strA = (p.sAo % 4 == 0) && (p.sAi % 4 == 0), strB = (p.sBo % 4 == 0) && (p.sBi % 4 == 0);
+    const bool kcA = p.layA == LAY_KC, kcB = p.layB == LAY_KC;
+    const bool okA = kcA ? (al16(p.A) && p.lda % 4 == 0 && strA) : true, okB = kcB ? (al16(p.B) && p.ldb % 4 == 0 && strB) : true;
+    const long tiles32 = (long)((p.M + QT - 1) / QT) * ((p.N + QT - 1) / QT);
+    return okA && okB && p.K % 8 == 0 && p.K >= 8 && tiles32 * p.batch * p.splitk <= 4096;
+}
+}  // namespace
+// split-operand (six bf16 part products, fp32-grade) form of the register-direct 32 x 32 kernel; false: the caller keeps its fp32 kernel
+bool gemm_small_x3_ok(const GemmP& p) {
+    if (p.film_gamma || p.a_bf16 || p.b_bf16 || !p.A || !p.B || !p.C || p.M <= 0 || p.N <= 0) return false;
+    if (p.splitk > 1 && (p.act != ACT_NONE || p.colmask)) return false;
+    return tiny_ok(p);
+}
+int gemm_small_x3(const GemmP& p, hipStream_t st) {
+    GG_REQUIRE(gemm_small_x3_ok(p), "gemm_small_x3: operands not aligned for the register-direct kernel");
+    int kchunk = (p.K + p.splitk - 1) / p.splitk;
+    kchunk = (kchunk + 15) / 16 * 16;
+    const long tiles32 = (long)((p.M + QT - 1) / QT) * ((p.N + QT - 1) / QT);
+    dim3 grid32((unsigned)tiles32, 1, (unsigned)(p.batch * p.splitk));
+    const bool kcA = p.layA == LAY_KC, kcB = p.layB == LAY_KC;
+#define GG_TINY3(LA_, LB_) hipLaunchKernelGGL((gemm_tiny_kernel<LA_, LB_, 3>), grid32, dim3(NT), 0, st, p, kchunk)
+    if (kcA && kcB) GG_TINY3(LAY_KC, LAY_KC);
+    else if (kcA) GG_TINY3(LAY_KC, LAY_KS);
+    else if (kcB) GG_TINY3(LAY_KS, LAY_KC);
+    else GG_TINY3(LAY_KS, LAY_KS);
+#undef GG_TINY3
+    GG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 bool gemm_small_wanted(const GemmP& p) {
     if (p.film_gamma || p.a_bf16 || p.b_bf16) return false;

@@ -76,5 +76,7 @@ int gemm_f32(const GemmP& p, hipStream_t st);    // exact fp32 (v_mfma_f32_32x32
 int gemm_bf16(const GemmP& p, hipStream_t st);   // bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16)
 bool gemm_small_wanted(const GemmP& p);          // few-tile problems: use the latency-optimised 64x64 / one-shot-K kernel
 int gemm_small(const GemmP& p, hipStream_t st);
+bool gemm_small_x3_ok(const GemmP& p);           // bf16x3 mode: the register-direct kernel with six bf16 part products (fp32-grade)
+int gemm_small_x3(const GemmP& p, hipStream_t st);
 
 }  // namespace gg
