@@ -90,6 +90,10 @@ SYMBOLS = {
     "gg_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_flash": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_tlin": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_ffn_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_test_ffn_fused": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_void_p]),
     "gg_set_sqx": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_bstore": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_wgrad": (C.c_int, [C.c_void_p, C.c_int]),

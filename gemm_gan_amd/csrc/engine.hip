@@ -186,6 +186,8 @@ struct gg_engine {
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
+    int ffn_on = getenv("GG_FFN_FUSED") != nullptr;   // fused feed-forward block (ffn.hip), bf16 mode, E = 256: opt-in (or gg_set_ffn_fused) -
+                               // measured 20 % slower than the two launches it replaces (profiles/r03_ffn_fused.md)
     float *s_dt, *s_dp, *s_dq, *s_dq2, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
     hipStream_t st = nullptr;
     // ---- captured train step (hipGraph) ----
@@ -921,30 +923,47 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 KL(k_add_layernorm_fwd(x_in, RB * S, L.r1, w + lp.n1w, w + lp.n1b, L.x1, L.st1, RB * S, E, dkey(e, a, n.role, l, 1), c.st));
             });
         }
-        {   // h = drop(relu(x1 W1^T + b1))
-            TlinP t;
-            t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
-            t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
-            t.y_bf16 = bst;
-            if (bst) maybe_fp8(e, n, t, lp.l1w);
-            if (bst) TLIN_MUST(t);
-            else TLIN_OR(t, {
-                GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
-                if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
-            });
+        bool ffn_done = false;
+        if (bst && !e->fp8_fwd && e->ffn_on) {   // x2 = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch: the hidden tile stays on chip
+            FfnP f;
+            f.X = L.x1; f.M = RB * S; f.E = E; f.F = F;
+            f.W1 = WB(n, lp.l1w); f.b1 = w + lp.l1b; f.W2T = WTB(n, lp.l2w); f.b2 = w + lp.l2b;
+            f.Hs = L.h; f.R2 = L.r2; f.keep_rows = keep_rows;
+            f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b; f.Y = L.x2; f.stats = L.st2;
+            f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
+            if (ffn_fused_supported(f)) {
+                const double tokd = (double)RB * S, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
+                ProfScope ps(c, "ffn_fused_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (4.0 * E + 4.0 * E) + kept * (2.0 * F + 4.0 * E) + 4.0 * E * F);
+                KL(ffn_fused(f, c.st));
+                ffn_done = true;
+            }
         }
-        {   // x2 = LN2(x1 + drop(h W2^T + b2))
-            TlinP t;
-            t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
-            t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
-            t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
-            t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
-            if (bst) maybe_fp8(e, n, t, lp.l2w);
-            if (bst) TLIN_MUST(t);
-            else TLIN_OR(t, {
-                GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
-                KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
-            });
+        if (!ffn_done) {
+            {   // h = drop(relu(x1 W1^T + b1))
+                TlinP t;
+                t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
+                t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
+                t.y_bf16 = bst;
+                if (bst) maybe_fp8(e, n, t, lp.l1w);
+                if (bst) TLIN_MUST(t);
+                else TLIN_OR(t, {
+                    GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
+                    if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
+                });
+            }
+            {   // x2 = LN2(x1 + drop(h W2^T + b2))
+                TlinP t;
+                t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
+                t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
+                t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
+                t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
+                if (bst) maybe_fp8(e, n, t, lp.l2w);
+                if (bst) TLIN_MUST(t);
+                else TLIN_OR(t, {
+                    GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
+                    KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
+                });
+            }
         }
         x_in = L.x2;
     }
@@ -2093,7 +2112,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2232,6 +2251,11 @@ int gg_set_prefetch(gg_engine* e, int on) {
 int gg_set_flash(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->flash = on != 0;
+    return 0;
+}
+int gg_set_ffn_fused(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->ffn_on = on != 0;
     return 0;
 }
 int gg_set_tlin(gg_engine* e, int on) {

@@ -151,6 +151,23 @@ int flash_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx, 
 int flash_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
                    int mask_B, void* dqkv, long N, int S, int E, int nh, DropKey drop, int io_bf16, hipStream_t st, long qkv_B = 0, hipEvent_t ev_mid = nullptr);
 
+// fused feed-forward block of an encoder layer, forward (ffn.hip): x2 = LN(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)), bf16 MFMA,
+// E = 256, F = 512; h (bf16) and the pre-LayerNorm sum r2 (fp32) are stored for rows < keep_rows only (-1: all)
+struct FfnP {
+    const float* X = nullptr; long M = 0;           // x1 [M, E] fp32: the input and the residual
+    int E = 0, F = 0;
+    const void* W1 = nullptr; const float* b1 = nullptr;     // bf16 [F][E]
+    const void* W2T = nullptr; const float* b2 = nullptr;    // bf16 W2^T [F][E] (the transposed shadow of linear2.weight [E][F])
+    void* Hs = nullptr;                             // bf16 [M, F]
+    float* R2 = nullptr;                            // fp32 [M, E]
+    long keep_rows = -1;
+    const float* ln_g = nullptr; const float* ln_b = nullptr; float* Y = nullptr; float* stats = nullptr;
+    DropKey drop1, drop2;                           // inner (element index = token * F + f) and post-FFN (token * E + n) dropout
+};
+bool ffn_fused_supported(const FfnP& p);
+int ffn_fused(const FfnP& p, hipStream_t st);
+void ffn_time_next(hipEvent_t begin, hipEvent_t end);
+
 // split-operand (bf16x3) attention of GG_PREC_BF16X3: fp32 qkv / ctx / dctx / dqkv, `ns` bf16 parts per MFMA operand (2: three
 // products per tile - the backward form; 3: six products, fp32-grade - the forward form); any S <= 2048 (keys / queries streamed)
 bool flash_attn_x3_supported(int S, int E, int nh);

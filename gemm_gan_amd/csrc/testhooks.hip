@@ -78,6 +78,18 @@ int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const f
                           make_drop_key(drop_p, drop_seed, drop_site, drop_call), io_bf16, (hipStream_t)stream, qkv_B, nullptr);
 }
 
+int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1, const void* W2T, const float* b2, void* Hs, float* R2,
+                      int64_t keep_rows, const float* ln_g, const float* ln_b, float* Y, float* stats, float drop_p, uint64_t drop_seed,
+                      uint32_t site1, uint32_t site2, uint32_t drop_call, void* stream) {
+    FfnP f;
+    f.X = X; f.M = M; f.E = 256; f.F = 512; f.W1 = W1; f.b1 = b1; f.W2T = W2T; f.b2 = b2; f.Hs = Hs; f.R2 = R2; f.keep_rows = keep_rows;
+    f.ln_g = ln_g; f.ln_b = ln_b; f.Y = Y; f.stats = stats;
+    f.drop1 = make_drop_key(drop_p, drop_seed, site1, drop_call);
+    f.drop2 = make_drop_key(drop_p, drop_seed, site2, drop_call);
+    GG_REQUIRE(ffn_fused_supported(f), "gg_test_ffn_fused: unsupported operands");
+    return ffn_fused(f, (hipStream_t)stream);
+}
+
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
                   int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,

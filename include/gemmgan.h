@@ -205,6 +205,7 @@ int gg_set_wgrad(gg_engine* e, int on);               /* long-reduction weight-g
 int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
+int gg_set_ffn_fused(gg_engine* e, int on);           /* fused feed-forward block (one launch per layer) in bf16 mode at E = 256 (default off: measured slower than the two launches) */
 int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
 int gg_get_optimizer_step(const gg_engine* e, int role); /* Adam/AdamW bias-correction step count   */
 int gg_set_optimizer_step(gg_engine* e, int role, int step);
@@ -254,6 +255,12 @@ int gg_test_attn_fwd(const void* qkv, const uint8_t* mask, int mask_B, void* ctx
 int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse2, float* delta, const uint8_t* mask,
                      int mask_B, void* dqkv, int64_t N, int S, int E, int nh, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                      uint32_t drop_call, int io_bf16, int64_t qkv_B, void* stream);
+/* fused feed-forward block (csrc/ffn.hip; torch transformer.py:961-983): X [M,256] fp32, W1 bf16 [512][256], W2T = bf16 W2^T [512][256];
+ * Hs bf16 [M,512] and R2 fp32 [M,256] written for rows < keep_rows (-1: all), Y = LayerNorm(R2) fp32, stats [M,2] (mean, rstd);
+ * dropout keys: (p, seed, site1, call) for the inner dropout, (p, seed, site2, call) for the post-FFN one */
+int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1, const void* W2T, const float* b2, void* Hs, float* R2,
+                      int64_t keep_rows, const float* ln_g, const float* ln_b, float* Y, float* stats, float drop_p, uint64_t drop_seed,
+                      uint32_t site1, uint32_t site2, uint32_t drop_call, void* stream);
 /* dW [N,K] += dY [M,N]^T X [M,K] over the token rows (+ optional FiLM on X, FiLM-gradient contraction, bias column sums) */
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,

@@ -611,3 +611,56 @@ def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
     check("dgamma", dg_d, (dy.double() * xh).sum(0), False)
     check("dbeta", db_d, dy.double().sum(0), False)
     check("fused bias gradient", dbias_d, dres.sum(0), False)        # column sums of the fp32 values, before the bf16 store
+
+
+# ---- fused feed-forward block ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,keep_rows,drop_on", [(8 * 257, -1, True), (8 * 257, 3 * 257, True), (5 * 257 + 3, 0, False), (70000, 1000, True)])
+def test_fused_feed_forward_block_equals_the_fp64_result(M, keep_rows, drop_on):
+    """ffn_fused_kernel (csrc/ffn.hip): x2 = LN(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch; the hidden tile goes from the
+    first product's accumulators straight into the second product's operand registers.  Reference on the values the MFMAs see:
+    x1 rounded to bf16 for the first product (fp32 for the residual), h rounded to bf16 (it is both stored and multiplied as bf16).
+    h (bf16): one rounding; r2, x2, statistics (fp32): 1e-4.  Rows >= keep_rows: h / r2 / statistics untouched.  M = 70 000: the
+    persistent grid walks several tiles per workgroup (chunk pipeline across tile boundaries) and ends in a ragged tile."""
+    lib = L.load()
+    E, F = 256, 512
+    g = torch.Generator().manual_seed(M + 5)
+    x1 = rnd(g, M, E)
+    W1, b1 = bf(rnd(g, F, E, scale=0.06)), rnd(g, F, scale=0.1)
+    W2, b2 = bf(rnd(g, E, F, scale=0.05)), rnd(g, E, scale=0.1)
+    gam, bet = 1 + rnd(g, E, scale=0.1), rnd(g, E, scale=0.1)
+    drop = (0.1, 31, 1012, 1013, 4) if drop_on else (0.0, 0, 0, 0, 0)
+    d = lambda t, dt=torch.float32: t.to(DEV, dt).contiguous()
+    x_d, W1_d, W2T_d = d(x1), d(W1, torch.bfloat16), d(W2.T, torch.bfloat16)
+    b1_d, b2_d, g_d, bt_d = d(b1), d(b2), d(gam), d(bet)
+    h_d = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    r2_d = torch.full((M, E), float("nan"), device=DEV)
+    y_d = torch.full((M, E), float("nan"), device=DEV)
+    st_d = torch.full((M, 2), float("nan"), device=DEV)
+    L.check(lib.gg_test_ffn_fused(P(x_d), M, P(W1_d), P(b1_d), P(W2T_d), P(b2_d), P(h_d), P(r2_d), keep_rows, P(g_d), P(bt_d), P(y_d), P(st_d),
+                                  C.c_float(drop[0]), drop[1], drop[2], drop[3], drop[4], stream()))
+    torch.cuda.synchronize()
+    ks = keep_scale(drop[0]) if drop_on else 1.0
+    h = (bf(x1) @ W1.T + b1.double()).clamp_min(0)
+    if drop_on:
+        k0, thr = drop_key(drop[0], drop[1], drop[2], drop[4])
+        h = h * torch.from_numpy(drop_keep(k0, thr, np.arange(M * F, dtype=np.int64)).reshape(M, F)).double() * ks
+    hb = bf(h.float())
+    y = hb @ W2.T + b2.double()
+    if drop_on:
+        k0, thr = drop_key(drop[0], drop[1], drop[3], drop[4])
+        y = y * torch.from_numpy(drop_keep(k0, thr, np.arange(M * E, dtype=np.int64)).reshape(M, E)).double() * ks
+    r2 = x1.double() + y
+    mu = r2.mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((r2 - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+    x2 = (r2 - mu) * rstd * gam.double() + bet.double()
+    kr = M if keep_rows < 0 else keep_rows
+    diag(f"== fused feed-forward block M={M} keep_rows={keep_rows} dropout={drop_on}")
+    # (an h element within fp32 accumulation noise of a bf16 rounding boundary rounds the other way than the float64 reference:
+    # one such element moves an output by 2^-8 |h w2| ~ 2e-4 of the row scale - hence the max-norm bound of 2e-3 beside rel-L2 1e-4)
+    check("x2 = LayerNorm(r2)", y_d, x2, False, 1e-4, 2e-3)
+    if kr > 0:
+        check("hidden activations (stored rows)", h_d[:kr], h[:kr], True)
+        check("pre-LayerNorm sum (stored rows)", r2_d[:kr], r2[:kr], False, 1e-4, 2e-3)
+        check("LayerNorm statistics", st_d[:kr].cpu(), torch.cat([mu, rstd], 1)[:kr], False)
+    if kr < M:
+        assert torch.isnan(h_d[kr:].float()).all() and torch.isnan(r2_d[kr:]).all() and torch.isnan(st_d[kr:]).all()
