@@ -88,6 +88,7 @@ struct CondActs {
     float drop = 0.f;
     bool flash = false;
     bool bst = false;          // qkv / ctx / h (and their gradients) stored as bf16 in this pass
+    bool xst = false;          // the LayerNorm outputs x1 (every layer) and x2 (all but the last layer) stored as bf16 in this pass
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     float *pe_h = nullptr, *pe_y = nullptr, *pe_st = nullptr, *pe_zero = nullptr;     // Linear->ReLU->LayerNorm patch encoder (img variant)
     uint8_t* mask;
@@ -224,9 +225,10 @@ struct gg_engine {
     std::vector<std::string> named_cls;
     bool prof_named_all = true;
     int prof_named_one = -1;
-    int str_cls[32] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
+    int str_cls[40] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
+    int xstore_on = getenv("GG_NO_XSTORE") == nullptr;   // bf16 storage of the encoder's LayerNorm outputs (production width, bf16 mode)
 };
 
 namespace {
@@ -716,13 +718,14 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
-            static const char* extra[16] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
+            static const char* extra[18] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
                                             "wst_ln_kernel<8,2,16,false,2>", "wst_ln_kernel<8,2,16,true,3>", "wst_ln_kernel<4,2,16,true,2>",
                                             "wst_ln_kernel<8,1,48,true,1>",
                                             "tlin_res16_kernel<8,256,true,1,true>", "tlin_str_kernel<256,false,true,0,true>",
                                             "tlin_str_kernel<256,false,true,1,true>", "wst_ln_kernel<4,2,16,true,0,true>",
                                             "wst_ln_kernel<8,1,32,true,0,true>", "wst_ln_kernel<8,2,16,false,2,true>",
-                                            "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>", "wst_ln_kernel<4,1,48,true,1,false,2>"};
+                                            "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>", "wst_ln_kernel<4,1,48,true,1,false,2>",
+                                            "wst_ln_kernel<8,2,16,true,2>", "wst_ln_kernel<4,2,16,true,2,false,3>"};
             if (kc >= 32) snprintf(nm, sizeof nm, "%s", extra[kc - 32]);
             else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
@@ -746,8 +749,8 @@ int try_tlin(Ctx& c, const TlinP& p) {
         // previous Y when accumulating, sign-mask reference, bf16 weights once
         const double MN = (double)p.M * p.N;
         const double MNy = (p.y_rows >= 0 && p.y_rows < p.M) ? (double)p.y_rows * p.N : MN;     // rows whose pre-LN sum is stored
-        r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MNy + (p.ln_g ? 4.0 * MN : 0.0) +
-                  (p.res ? 4.0 * MN : 0.0) + (p.accumulate ? 4.0 * MN : 0.0) + (p.mask_ref ? (p.mask_bf16 ? 2.0 : 4.0) * MN : 0.0) +
+        r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MNy + (p.ln_g ? (p.ln_y_bf16 ? 2.0 : 4.0) * MN : 0.0) +
+                  (p.res ? (p.res_bf16 ? 2.0 : 4.0) * MN : 0.0) + (p.accumulate ? 4.0 * MN : 0.0) + (p.mask_ref ? (p.mask_bf16 ? 2.0 : 4.0) * MN : 0.0) +
                   2.0 * p.N * p.K;
         r.e0 = e->prof_pool[e->prof_next++];
         r.e1 = e->prof_pool[e->prof_next++];
@@ -845,6 +848,14 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // must be a tlin / flash kernel, which holds for E in {64,128,256} (see tlin_supported)
     const bool bst = e->bstore_on && !e->x3 && use_flash && use_tlin(e) && (E == 64 || E == 128 || E == 256);
     a.bst = bst;
+    // The LayerNorm outputs inside the encoder are read as MFMA operands (QKV, FFN1, the two weight-gradient products: rounded to
+    // bf16 on load anyway) and as the residual of the next sub-block: at the production width, where every one of those
+    // consumers is a weight-stationary kernel, they are stored ONCE, in bf16 (half the bytes on six passes per layer).  The
+    // pre-LayerNorm sums r1 / r2 and the statistics stay fp32 (LayerNorm backward), and so does the last layer's output
+    // (cross-attention and CLS read it as fp32).
+    static const bool wst_env = getenv("GG_NO_WST") == nullptr && getenv("GG_NO_WST2") == nullptr && getenv("GG_NO_WST_QKV") == nullptr;
+    const bool xst = bst && e->xstore_on && wst_env && !e->fp8_fwd && E == 256 && F == 2 * E;
+    a.xst = xst;
     // The replicas differ only by their dropout draws, and nothing is dropped before the first attention: the layer-0
     // input x0 and its QKV projection are the same for all of them.  With the fused kernels (row / sample indices taken
     // modulo the un-replicated size) neither the R-fold copy of x0 nor R-1 of the R projections exist.
@@ -873,7 +884,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             TlinP t;
             const bool shared = share0 && l == 0;
             t.X = x_in; t.ldx = E; t.M = shared ? (long)B * S : RB * S; t.W = WB(n, lp.sa.inw); t.ldw = E; t.bias = w + lp.sa.inb;
-            t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E; t.y_bf16 = bst;
+            t.Y = L.qkv; t.ldy = 3 * E; t.N = 3 * E; t.K = E; t.y_bf16 = bst; t.x_bf16 = xst && l > 0;
             if (bst) maybe_fp8(e, n, t, lp.sa.inw);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, GG_TRY(lin_fwd(c, x_in, E, w + lp.sa.inw, E, w + lp.sa.inb, L.qkv, 3 * E, (int)(RB * S), 3 * E, E)));
@@ -916,6 +927,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
             t.res = x_in; t.ldres = E; t.res_rows = (share0 && l == 0) ? (long)B * S : RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
+            t.res_bf16 = xst && l > 0; t.ln_y_bf16 = xst;
             if (bst) maybe_fp8(e, n, t, lp.sa.ow);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
@@ -924,7 +936,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             });
         }
         bool ffn_done = false;
-        if (bst && !e->fp8_fwd && e->ffn_on) {   // x2 = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch: the hidden tile stays on chip
+        if (bst && !xst && !e->fp8_fwd && e->ffn_on) {   // x2 = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch: the hidden tile stays on chip
             FfnP f;
             f.X = L.x1; f.M = RB * S; f.E = E; f.F = F;
             f.W1 = WB(n, lp.l1w); f.b1 = w + lp.l1b; f.W2T = WTB(n, lp.l2w); f.b2 = w + lp.l2b;
@@ -943,7 +955,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 TlinP t;
                 t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
                 t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
-                t.y_bf16 = bst;
+                t.y_bf16 = bst; t.x_bf16 = xst;
                 if (bst) maybe_fp8(e, n, t, lp.l1w);
                 if (bst) TLIN_MUST(t);
                 else TLIN_OR(t, {
@@ -957,6 +969,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
                 t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
                 t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
+                t.res_bf16 = xst; t.ln_y_bf16 = xst && l + 1 < e->nl;
                 if (bst) maybe_fp8(e, n, t, lp.l2w);
                 if (bst) TLIN_MUST(t);
                 else TLIN_OR(t, {
@@ -1273,7 +1286,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         {
             Ctx cs = c;
             const bool fk = side_begin(c, cs);
-            GG_TRY(lin_bwd_weight(cs, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, 0, nullptr, g + lp.l1b));
+            GG_TRY(lin_bwd_weight(cs, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, a.xst, nullptr, g + lp.l1b));
             GG_TRY(side_end(c, fk, 1));
         }
         {   // dx1 = dr2 + dhpre W1
@@ -1379,7 +1392,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         {
             Ctx cs = c;
             const bool fk = side_begin(c, cs);
-            GG_TRY(lin_bwd_weight(cs, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, 0, nullptr, g + lp.sa.inb,
+            GG_TRY(lin_bwd_weight(cs, e->sdqkv, 3 * E, x_in, E, g + lp.sa.inw, E, (int)(RB * S), 3 * E, E, bst, a.xst && l > 0, nullptr, g + lp.sa.inb,
                                   shared ? (long)B * S : 0));
             GG_TRY(side_end(c, fk, 2));
         }
@@ -2112,7 +2125,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2273,6 +2286,11 @@ int gg_set_bstore(gg_engine* e, int on) {
     e->bstore_on = on != 0;
     return 0;
 }
+int gg_set_xstore(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->xstore_on = on != 0;
+    return 0;
+}
 int gg_debug_buffer_is_bf16(gg_engine* e, const char* name) {
     if (!e || !name) return -1;
     std::string s(name);
@@ -2280,6 +2298,7 @@ int gg_debug_buffer_is_bf16(gg_engine* e, const char* name) {
         const CondActs& a = s[0] == 'G' ? e->actsG : e->actsD;
         const std::string k = s.substr(5);
         if (a.bst && (k == "qkv" || k == "ctx" || k == "h")) return 1;
+        if (a.xst && (k == "x1" || (k == "x2" && s[3] - '0' + 1 < e->nl))) return 1;
     }
     return 0;
 }

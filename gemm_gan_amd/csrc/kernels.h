@@ -196,6 +196,8 @@ struct TlinP {
     int accumulate = 0;                             // y += previous content
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
+    int res_bf16 = 0, ln_y_bf16 = 0;                // weight-stationary LN kernels only: the residual rows / the LayerNorm output are bf16 arrays (same strides in
+                                                    // elements): the encoder's LN outputs feed only MFMA operands and residual adds, so they are stored once, in bf16
     // fp8 (OCP e4m3) operands: W points at the e4m3 shadow copy (ldw in elements), *w_exp (device) is its per-tensor
     // power-of-two exponent (stored value = w * 2^w_exp), activations are quantised as x * 2^x_exp on load
     int fp8 = 0; const int* w_exp = nullptr; int x_exp = 0;

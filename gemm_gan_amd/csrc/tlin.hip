@@ -992,6 +992,7 @@ inline bool needs_resident(const TlinP& p) { return p.ln_g || p.res || !(p.K == 
 
 // supported instantiations: stream K in {64,128,256} (any N % 32 == 0);
 // resident (N, K-slice) in {(256, 256), (128, 128), (64, 64)} with K a multiple of the slice
+bool wst_routed(const TlinP& p);
 bool tlin_supported(const TlinP& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
     if (p.N % 32 || p.K % 64) return false;
@@ -1002,6 +1003,7 @@ bool tlin_supported(const TlinP& p) {
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
     if (p.y_bf16 && p.accumulate) return false;
+    if ((p.res_bf16 || p.ln_y_bf16) && !(wst_routed(p) && wst_ln_supported(p))) return false;      // bf16 residual / LN output: wst.hip only
     if (p.drop.p > 0.f && p.drop_ld % 2) return false;      // the epilogues hash element PAIRS (drop_rng.h)
     if (!needs_resident(p)) return (size_t)p.N * 4 <= 64 * 1024;     // bias vector in LDS
     if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue

@@ -163,11 +163,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         f32x4 res[EPI == EPI_LN || EPI == EPI_ACC ? RT : 1][4];
         u32x4 mref[EPI == EPI_MASK ? RT : 1][2];
         if constexpr (EPI == EPI_LN) {
-            const float* resp = p.res + (long)(tokc % (int)p.res_rows) * p.ldres + f0 + 16 * h;
+            if (p.res_bf16) {
+                const __bf16* resp = reinterpret_cast<const __bf16*>(p.res) + (long)(tokc % (int)p.res_rows) * p.ldres + f0 + 16 * h;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt) {          // 16 bf16 values in the first two of the four fp32 quads' registers
+                    res[rt][0] = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(resp + 32 * rt));
+                    res[rt][1] = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(resp + 32 * rt + 8));
+                }
+            } else {
+                const float* resp = p.res + (long)(tokc % (int)p.res_rows) * p.ldres + f0 + 16 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(resp + 32 * rt + 4 * g);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(resp + 32 * rt + 4 * g);
+            }
         }
         if constexpr (EPI == EPI_ACC) {
             const float* yo = reinterpret_cast<const float*>(p.Y) + (long)tokc * p.ldy + gcol + f0 + 16 * h;
@@ -275,7 +284,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
-                v += res[rt][g];
+                if (p.res_bf16) {
+                    const u32x4 rw = __builtin_bit_cast(u32x4, res[rt][g >> 1]);
+                    const unsigned w0 = rw[2 * (g & 1)], w1 = rw[2 * (g & 1) + 1];
+                    v += f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                               __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+                } else {
+                    v += res[rt][g];
+                }
                 if (valid && keep_y) *reinterpret_cast<f32x4*>(yb + 32 * rt + 4 * g) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -302,8 +318,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         const float var = fmaxf(t2 * (1.f / N) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + LN_EPS);
         float* const lb = p.ln_y + (long)tokc * p.ldy + f0 + 16 * h;
+        __bf16* const lbh = reinterpret_cast<__bf16*>(p.ln_y) + (long)tokc * p.ldy + f0 + 16 * h;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
+            unsigned packed[8];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = f0 + 32 * rt + 16 * h + 4 * g;
@@ -312,7 +330,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
                 f32x4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = (acc[rt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
-                if (valid) *reinterpret_cast<f32x4*>(lb + 32 * rt + 4 * g) = y;
+                if (!p.ln_y_bf16 && valid) *reinterpret_cast<f32x4*>(lb + 32 * rt + 4 * g) = y;
+                packed[2 * g] = pack2(y[0], y[1]);
+                packed[2 * g + 1] = pack2(y[2], y[3]);
+            }
+            if (p.ln_y_bf16 && valid) {
+                *reinterpret_cast<u32x4*>(lbh + 32 * rt) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+                *reinterpret_cast<u32x4*>(lbh + 32 * rt + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
             }
         }
         if (wave == 0 && h == 0 && valid && keep_y) {
@@ -364,6 +388,7 @@ bool wst_ln_supported(const TlinP& p) {
     if (p.N != 256 || (p.K != 256 && p.K != 512) || p.M < 1) return false;
     if (p.accumulate || p.mask_ref || p.act_relu || p.y_bf16 || p.film_g || p.y_row_group) return false;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || !al16(p.res) || !al16(p.ln_y) || p.ldx % 8 || p.ldw % 8 || p.ldy % 4 || p.ldres % 4) return false;
+    if ((p.res_bf16 && p.ldres % 8) || (p.ln_y_bf16 && p.ldy % 8)) return false;
     if (p.drop.p > 0.f && p.drop_ld % 2) return false;
     return true;
 }
@@ -382,6 +407,7 @@ int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
 //   5  as 1 with K = 768                                                 (dx += dqkv Win)
 //   6  y (bf16) = X W^T + b, N = 768 = 3 column groups of 256, K = 256, fp32 X   (packed QKV projection, forward)
 //   7  as 5 (K = 768) as 2 column groups of 128                          (dx += dqkv Win)
+//   8 / 9  as 2 / 6 with bf16 X (the LayerNorm outputs stored in bf16: engine.hip "xst")
 int wst_kind(const TlinP& p) {
     if (p.fp8 || p.ln_g || p.res || p.film_g || p.y_row_group || p.M < 1) return 0;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 8 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
@@ -399,11 +425,11 @@ int wst_kind(const TlinP& p) {
         p.drop.p == 0.f && !p.bias && p.ldy % 4 == 0)
         return p.K == 512 ? 1 : 5;
     if (!p.accumulate && !p.mask_ref && p.y_bf16 && p.x_bf16 && p.N == 256 && p.K == 256 && p.ldy % 8 == 0) return 4;
-    if (!p.accumulate && !p.mask_ref && p.y_bf16 && !p.x_bf16 && p.N == 512 && p.K == 256 && p.ldy % 8 == 0) return 2;
+    if (!p.accumulate && !p.mask_ref && p.y_bf16 && p.N == 512 && p.K == 256 && p.ldy % 8 == 0) return p.x_bf16 ? 8 : 2;
     static const bool no_qkv = getenv("GG_NO_WST_QKV") != nullptr;
-    if (!no_qkv && !p.accumulate && !p.mask_ref && p.y_bf16 && !p.x_bf16 && p.N == 768 && p.K == 256 && p.ldy % 8 == 0 && !p.act_relu &&
+    if (!no_qkv && !p.accumulate && !p.mask_ref && p.y_bf16 && p.N == 768 && p.K == 256 && p.ldy % 8 == 0 && !p.act_relu &&
         p.drop.p == 0.f)
-        return 6;
+        return p.x_bf16 ? 9 : 6;
     if (!p.accumulate && p.mask_ref && p.mask_bf16 && p.y_bf16 && p.x_bf16 && p.N == 512 && p.K == 256 && !p.act_relu &&
         p.drop.p == 0.f && !p.bias && p.ldy % 8 == 0 && p.ldref % 8 == 0 && al16(p.mask_ref))
         return 3;
@@ -442,6 +468,8 @@ int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         case 5: return launch<8, 1, 48, true, EPI_ACC>(p, st, ev0, ev1);
         case 6: return launch<4, 2, 16, false, EPI_ACT, false, 3>(p, st, ev0, ev1);
         case 7: return launch<4, 1, 48, true, EPI_ACC, false, 2>(p, st, ev0, ev1);
+        case 8: return launch<8, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
+        case 9: return launch<4, 2, 16, true, EPI_ACT, false, 3>(p, st, ev0, ev1);
     }
     set_error("wst_other: no instantiation for this call");
     return -2;

@@ -410,13 +410,15 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
             # the hidden activations of the forward-only replica (the third of the critic's three) are not stored by the fused
             # feed-forward kernel: no backward pass reads them
             u, v = u.view(-1, F_)[: 2 * B * S_], v.view(-1, F_)[: 2 * B * S_]
-        ck.check(n, u, v, tol=6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx") else None)
+        # x1 / x2 (all but the last layer's) are bf16-stored too at the production width (one 2^-9 rounding; the rounded residual moves
+        # the last layer's fp32 output and the conditioning vector by a little over 2e-3 of their largest element)
+        ck.check(n, u, v, tol=6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx", "x1", "x2", "c") else None)
     for n in gnames:
         # the critic's conditioning vector differs by ~5e-4 between the two bf16 paths (values that sit on a bf16
         # rounding boundary re-round differently); on these 6-12 sample batches that flips a few ReLU gates of
         # the critic head, which moves d(loss)/d(x_fake) and everything downstream by percents
         ck.check("generator pass " + n, a["gen:" + n], b["gen:" + n],
-                 tol=0.25 if n in ("dxfake", "dc") else (6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx") else None))
+                 tol=0.25 if n in ("dxfake", "dc") else (6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx", "x1", "x2", "c") else None))
     for k in a["gstate"]:
         from gpu_util import diag as _d
         _d(f"      dG {k:60s} cos {_cos(a['gstate'][k], b['gstate'][k]):.6f}")
@@ -425,7 +427,50 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     from gpu_util import diag
     cd, cg = _cos(a["g"], b["g"]), _cos(a["gg"], b["gg"])
     diag(f"   flat gradient cosine tlin vs generic: critic {cd:.6f} generator {cg:.6f}")
-    assert cd > 0.999 and cg > 0.99, (cd, cg)
+    # 0.997: with the bf16-stored LayerNorm outputs the rounded residual flips as many FFN gates again as the operand rounding does
+    # (tests/test_gate_flips_gpu.py holds the gates fixed and bounds what is left at 1e-2); measured 0.9982 at dropout 0.1
+    assert cd > 0.997 and cg > 0.99, (cd, cg)
+    ck.done()
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_bf16_storage_of_the_layernorm_outputs_changes_only_the_residual_rounding(dropout):
+    """engine.hip "xst": at the production width the encoder's LayerNorm outputs x1 (both layers) and x2 (all but the last) are
+    stored in bf16.  Their MFMA consumers round to bf16 on load anyway (identical products); the only new rounding is the residual
+    operand of the next sub-block: stored values equal the fp32 ones to one bf16 rounding (2^-9), downstream fp32 tensors move by
+    parts in a thousand, losses and the gradient direction stay put."""
+    c = CASES["hot_tiles_E256"]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_dropout(dropout)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    names = ["D.L0.x1", "D.L0.x2", "D.L1.x1", "D.L1.x2", "D.c"]
+    out = {}
+    for on in (False, True):
+        eng.set_xstore(on)
+        eng.set_seed(5)
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(),
+                       **{n: eng.debug_buffer(n) for n in names},
+                       **{"bf16:" + n: eng.lib.gg_debug_buffer_is_bf16(eng.h, n.encode()) for n in names})
+    a, b = out[True], out[False]
+    assert [a["bf16:" + n] for n in names] == [1, 1, 1, 0, 0] and not any(b["bf16:" + n] for n in names)     # the last layer's output stays fp32
+    ck = Checker(f"bf16 LayerNorm-output storage on vs off, dropout={dropout}", 6e-3, metric="max")
+    for n in names:
+        ck.check(n, a[n].float(), b[n])
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=1e-2)
+    cs = _cos(a["g"], b["g"])
+    from gpu_util import diag
+    diag(f"   flat critic gradient cosine bf16 LN-output storage on vs off: {cs:.6f}")
+    assert cs > 0.997, cs           # gate flips on this 6-sample batch (see test_gate_flips_gpu.py); measured 0.9981 at dropout 0.1
     ck.done()
 
 
@@ -449,6 +494,7 @@ def test_fused_feed_forward_route_matches_the_two_launch_route(dropout):
     alpha = torch.rand(B, generator=g).cuda()
     names = ["D.L0.x1", "D.L0.h", "D.L0.x2", "D.L1.x2", "D.c"]
     out = {}
+    eng.set_xstore(False)          # the fused kernel reads x1 as fp32: the engine uses it only without bf16 LayerNorm-output storage
     for on in (False, True):
         eng.set_ffn_fused(on)
         eng.set_seed(5)
@@ -509,7 +555,7 @@ def test_bf16_operand_storage_is_numerically_transparent(case):
     cs = _cos(a["g"], b["g"])
     from gpu_util import diag
     diag(f"   flat critic gradient cosine bf16-storage on vs off: {cs:.6f}")
-    assert cs > 0.999, cs
+    assert cs > 0.997, cs           # E = 256: bf16 storage includes the LayerNorm outputs (residual rounding -> gate flips); measured 0.9982
     ck.done()
 
 
