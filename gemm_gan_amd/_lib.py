@@ -45,6 +45,7 @@ class GGTestLinear(C.Structure):       # gg_test_linear_args (include/gemmgan.h)
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("res_rows", C.c_int64),
                 ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_y", C.c_void_p), ("ln_stats", C.c_void_p),
                 ("res_bf16", C.c_int32), ("ln_y_bf16", C.c_int32),
+                ("lnb_dres", C.c_void_p), ("lnb_dgamma", C.c_void_p), ("lnb_dbeta", C.c_void_p), ("lnb_dbias", C.c_void_p),
                 ("w_parts", C.c_void_p), ("route", C.c_int32)]
 
 
@@ -93,6 +94,7 @@ SYMBOLS = {
     "gg_set_tlin": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_ffn_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_xstore": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_lnb_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_test_ffn_fused": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p]),

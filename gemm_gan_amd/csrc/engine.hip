@@ -180,8 +180,8 @@ struct gg_engine {
     // weight gradients are leaves of the backward chain: they run on a second stream beside the data-gradient kernels
     hipStream_t side = nullptr;
     bool side_own = true, pre_own = true;      // false: the stream was bound by the host (gg_bind_streams) and outlives the engine
-    hipEvent_t ev_ready = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool side_pending[4] = {false, false, false, false};
+    hipEvent_t ev_ready = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool side_pending[5] = {false, false, false, false, false};
     int side_on = 1;
     int prefetch_on = 1;       // gg_train_step computes the generator outputs of all critic iterations in batched passes
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
@@ -228,6 +228,7 @@ struct gg_engine {
     int str_cls[40] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
+    int lnb_on = getenv("GG_NO_WST_LNB") == nullptr;      // dx1 += and LN1 backward in one weight-stationary kernel (production width, bf16 mode)
     int xstore_on = getenv("GG_NO_XSTORE") == nullptr;   // bf16 storage of the encoder's LayerNorm outputs (production width, bf16 mode)
 };
 
@@ -718,14 +719,14 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
-            static const char* extra[18] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
+            static const char* extra[19] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
                                             "wst_ln_kernel<8,2,16,false,2>", "wst_ln_kernel<8,2,16,true,3>", "wst_ln_kernel<4,2,16,true,2>",
                                             "wst_ln_kernel<8,1,48,true,1>",
                                             "tlin_res16_kernel<8,256,true,1,true>", "tlin_str_kernel<256,false,true,0,true>",
                                             "tlin_str_kernel<256,false,true,1,true>", "wst_ln_kernel<4,2,16,true,0,true>",
                                             "wst_ln_kernel<8,1,32,true,0,true>", "wst_ln_kernel<8,2,16,false,2,true>",
                                             "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>", "wst_ln_kernel<4,1,48,true,1,false,2>",
-                                            "wst_ln_kernel<8,2,16,true,2>", "wst_ln_kernel<4,2,16,true,2,false,3>"};
+                                            "wst_ln_kernel<8,2,16,true,2>", "wst_ln_kernel<4,2,16,true,2,false,3>", "wst_ln_kernel<8,1,32,true,4>"};
             if (kc >= 32) snprintf(nm, sizeof nm, "%s", extra[kc - 32]);
             else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
@@ -751,7 +752,7 @@ int try_tlin(Ctx& c, const TlinP& p) {
         const double MNy = (p.y_rows >= 0 && p.y_rows < p.M) ? (double)p.y_rows * p.N : MN;     // rows whose pre-LN sum is stored
         r.bytes = (p.x_bf16 ? 2.0 : 4.0) * (double)p.M * p.K + (p.y_bf16 ? 2.0 : 4.0) * MNy + (p.ln_g ? (p.ln_y_bf16 ? 2.0 : 4.0) * MN : 0.0) +
                   (p.res ? (p.res_bf16 ? 2.0 : 4.0) * MN : 0.0) + (p.accumulate ? 4.0 * MN : 0.0) + (p.mask_ref ? (p.mask_bf16 ? 2.0 : 4.0) * MN : 0.0) +
-                  2.0 * p.N * p.K;
+                  2.0 * p.N * p.K + (p.lnb_dres ? 2.0 * MN : 0.0);
         r.e0 = e->prof_pool[e->prof_next++];
         r.e1 = e->prof_pool[e->prof_next++];
         tlin_time_next(r.e0, r.e1);           // dispatch timestamps of the kernel itself (what rocprofv3 reports), no barrier packets
@@ -1059,7 +1060,8 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
 // and bubbles get filled).  side_begin: the side stream waits for everything enqueued so far on the caller's stream;
 // side_end(slot): marks the launch; side_wait(slot): the caller's stream waits for it - called before the kernel that
 // OVERWRITES a buffer the pending launch reads (slot 0: sdres, 1: sdh, 2: sdqkv; 3: head / gradient-penalty parameter
-// gradients, whose operands live until the next iteration) and at the end of the backward.
+// gradients, whose operands live until the next iteration; 4: the second bf16 image in sdres, LN1's branch gradient when the
+// fused += / LayerNorm-backward kernel writes it) and at the end of the backward.
 // The engine's own streams run at the default priority: A/B runs with the device's lowest / highest stream priority
 // (GG_SIDE_PRIO=low|high) measured 38.4 / 39.0 ms per step against 38.2 at the default.
 bool create_side_stream(hipStream_t* s) {
@@ -1077,7 +1079,7 @@ bool side_begin(Ctx& c, Ctx& cs) {
     if (!e->ev_ready) {
         if (!e->side && !create_side_stream(&e->side)) return false;
         bool ok = hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 5; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { e->side_on = 0; return false; }
     }
     if (hipEventRecord(e->ev_ready, c.st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_ready, 0) != hipSuccess) return false;
@@ -1111,7 +1113,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const int bst = a.bst ? 1 : 0;
 
     if (e->no_cond) {        // nothing upstream of the (zero) conditioning vector; join the head's side-stream leaves
-        for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));
+        for (int i = 0; i < 5; ++i) GG_TRY(side_wait(c, i));
         return 0;
     }
     bool i2t_sh = false;
@@ -1289,16 +1291,35 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             GG_TRY(lin_bwd_weight(cs, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, a.xst, nullptr, g + lp.l1b));
             GG_TRY(side_end(c, fk, 1));
         }
-        {   // dx1 = dr2 + dhpre W1
+        // dx1 = dr2 + dhpre W1, then LN1 backward.  At the production width both run in ONE weight-stationary kernel (wst.hip EPI_LNB): dx1
+        // never travels (a 4-byte write and read per element less, one launch less); LN1's branch gradient goes to the second bf16
+        // image inside sdres, so the kernel does not have to wait for the weight-gradient launch that still reads LN2's.
+        float* dres1 = e->sdres;
+        bool lnb = false;
+        {
             TlinP t;
             t.X = e->sdh; t.ldx = F; t.M = RB * S; t.W = WTB(n, lp.l1w); t.ldw = F;
             t.Y = e->sdr; t.ldy = E; t.N = E; t.K = F; t.accumulate = 1; t.x_bf16 = bst;
-            if (bst) TLIN_MUST(t);
+            if (bst && e->lnb_on) {
+                TlinP u = t;
+                u.res = L.r1; u.ldres = E; u.res_rows = RB * S; u.ln_stats = L.st1; u.ln_g = w + lp.n1w; u.ln_y = dx;
+                u.lnb_dres = reinterpret_cast<__bf16*>(e->sdres) + RB * S * E;
+                u.lnb_dgamma = g + lp.n1w; u.lnb_dbeta = g + lp.n1b; u.lnb_dbias = g + lp.sa.ob;
+                u.drop = dkey(e, a, n.role, l, 1); u.drop_ld = E;
+                if (use_tlin(e) && tlin_supported(u)) {
+                    GG_TRY(side_wait(c, 4));
+                    TLIN_MUST(u);
+                    lnb = true;
+                    dres1 = reinterpret_cast<float*>(u.lnb_dres);
+                }
+            }
+            if (lnb) {
+            } else if (bst) TLIN_MUST(t);
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdh, F, w + lp.l1w, E, e->sdr, E, (int)(RB * S), F, E, 1)));
         }
         // LN1
-        GG_TRY(side_wait(c, 0));
-        {
+        if (!lnb) {
+            GG_TRY(side_wait(c, 0));
             ProfScope ps(c, "ln_bwd_v4_k", 16.0 * RB * S * E, (double)RB * S * (E * (12.0 + (bst ? 2.0 : 4.0)) + 8.0));
             KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
                                dkey(e, a, n.role, l, 1), c.st, bst));
@@ -1307,15 +1328,15 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         {
             Ctx cs = c;
             const bool fk = side_begin(c, cs);
-            GG_TRY(lin_bwd_weight(cs, e->sdres, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
-            GG_TRY(side_end(c, fk, 0));
+            GG_TRY(lin_bwd_weight(cs, dres1, E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
+            GG_TRY(side_end(c, fk, lnb ? 4 : 0));
         }
         {
             TlinP t;
-            t.X = e->sdres; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.sa.ow); t.ldw = E;
+            t.X = dres1; t.ldx = E; t.M = RB * S; t.W = WTB(n, lp.sa.ow); t.ldw = E;
             t.Y = e->sdctx; t.ldy = E; t.N = E; t.K = E; t.x_bf16 = bst; t.y_bf16 = bst;
             if (bst) TLIN_MUST(t);
-            else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdres, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
+            else TLIN_OR(t, GG_TRY(lin_bwd_data(c, dres1, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
         }
         const DropKey kA = dkey(e, a, n.role, l, 0);
         GG_TRY(side_wait(c, 2));
@@ -1421,7 +1442,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         KL(k_act_bwd(e->s_dx0, a.pe_h, (long)B * P * E, 0.f, 1.f, c.st));
         GG_TRY(lin_bwd_weight(c, e->s_dx0, E, in->patches, Dp, g + n.pe_w, Dp, B * P, E, Dp));
         KL(k_colsum(e->s_dx0, (long)B * P, E, E, g + n.pe_b, c.st));
-        for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));
+        for (int i = 0; i < 5; ++i) GG_TRY(side_wait(c, i));
         return 0;
     }
     if (wgrad_film_ok(e, e->s_demb, E, in->patches, Dp, B * P, E, Dp, P)) {
@@ -1461,7 +1482,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(lin_bwd_weight(c, dtok, E, in->text, Dt, g + n.te_w, Dt, B * T, E, Dt));
         KL(k_colsum(dtok, (long)B * T, E, E, g + n.te_b, c.st));
     }
-    for (int i = 0; i < 4; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
+    for (int i = 0; i < 5; ++i) GG_TRY(side_wait(c, i));      // the gradient buffer is complete on the caller's stream again
     return 0;
 }
 
@@ -1906,7 +1927,7 @@ void gg_destroy(gg_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->ev_ready) {
         (void)hipEventDestroy(e->ev_ready);
-        for (int i = 0; i < 4; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
+        for (int i = 0; i < 5; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     }
     if (e->side && e->side_own) (void)hipStreamDestroy(e->side);
     delete e;
@@ -2125,7 +2146,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2284,6 +2305,11 @@ int gg_set_wgrad(gg_engine* e, int on) {
 int gg_set_bstore(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->bstore_on = on != 0;
+    return 0;
+}
+int gg_set_lnb_fused(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->lnb_on = on != 0;
     return 0;
 }
 int gg_set_xstore(gg_engine* e, int on) {

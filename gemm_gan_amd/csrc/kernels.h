@@ -196,6 +196,11 @@ struct TlinP {
     int accumulate = 0;                             // y += previous content
     const float* res = nullptr; long ldres = 0; long res_rows = 1;             // + res[token % res_rows]
     const float* ln_g = nullptr; const float* ln_b = nullptr; float* ln_y = nullptr; float* ln_stats = nullptr;
+    // weight-stationary "+= then LayerNorm backward" (wst.hip EPI_LNB; N = 256, K = 512):  dy = Y + X W^T is the gradient w.r.t. a LayerNorm
+    // output whose pre-LN sum is `res` (fp32) with statistics `ln_stats` (read) and weight `ln_g`; written: ln_y = dr (gradient w.r.t.
+    // the pre-LN sum, fp32), lnb_dres = bf16(dr * dropout mask / (1-p)) (the branch gradient; key `drop`, stride drop_ld), and the
+    // column sums lnb_dgamma += sum dy*xhat, lnb_dbeta += sum dy, lnb_dbias += sum of the masked dr (atomic adds)
+    void* lnb_dres = nullptr; float* lnb_dgamma = nullptr; float* lnb_dbeta = nullptr; float* lnb_dbias = nullptr;
     int res_bf16 = 0, ln_y_bf16 = 0;                // weight-stationary LN kernels only: the residual rows / the LayerNorm output are bf16 arrays (same strides in
                                                     // elements): the encoder's LN outputs feed only MFMA operands and residual adds, so they are stored once, in bf16
     // fp8 (OCP e4m3) operands: W points at the e4m3 shadow copy (ldw in elements), *w_exp (device) is its per-tensor

@@ -32,6 +32,7 @@ int gg_test_linear(const gg_test_linear_args* a, int32_t* kernel_class, void* st
     p.res = a->res; p.ldres = a->ldres; p.res_rows = a->res_rows > 0 ? a->res_rows : 1;
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.ln_y = a->ln_y; p.ln_stats = a->ln_stats;
     p.res_bf16 = a->res_bf16; p.ln_y_bf16 = a->ln_y_bf16;
+    p.lnb_dres = a->lnb_dres; p.lnb_dgamma = a->lnb_dgamma; p.lnb_dbeta = a->lnb_dbeta; p.lnb_dbias = a->lnb_dbias;
     if (a->route == 2 || a->route == 3) {       // split-operand Linear: fp32 X, fp32 W, fp32 Y; 2 / 3 operand parts (3 / 6 products)
         GG_REQUIRE(a->w_parts && a->ldw == a->K, "gg_test_linear: routes 2 / 3 need the part scratch and a dense W");
         GG_TRY(k_split_weights(reinterpret_cast<const float*>(a->W), a->w_parts, (long)a->N * a->K, (long)a->N * a->K, a->route, (hipStream_t)stream));

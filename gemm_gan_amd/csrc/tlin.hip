@@ -995,6 +995,7 @@ inline bool needs_resident(const TlinP& p) { return p.ln_g || p.res || !(p.K == 
 bool wst_routed(const TlinP& p);
 bool tlin_supported(const TlinP& p) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
+    if (p.lnb_dres) return wst_routed(p) && wst_kind(p) == 10;        // += then LayerNorm backward: wst.hip only
     if (p.N % 32 || p.K % 64) return false;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldx % (p.x_bf16 ? 8 : 4) || p.ldy % 4 || p.ldw % 8) return false;
     if (p.bias && !al16(p.bias)) return false;

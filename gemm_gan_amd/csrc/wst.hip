@@ -36,7 +36,37 @@ constexpr int TT = 32;                                  // tokens per tile
 
 __device__ __forceinline__ int a_row_of_lane(int r) { return 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3); }
 
-enum { EPI_LN = 0, EPI_ACC = 1, EPI_ACT = 2, EPI_MASK = 3 };
+enum { EPI_LN = 0, EPI_ACC = 1, EPI_ACT = 2, EPI_MASK = 3, EPI_LNB = 4 };
+
+// Column sums over the 32 token lanes of a half-wave for 16 per-lane values (one feature each): a reduce-scatter butterfly -
+// every step halves the number of values a lane carries - so 16 shuffles instead of 80.  Returns, in every lane, the total of value
+// index 8*b4 + 4*b3 + 2*b2 + b1 (b_k = bit k of the lane's token index c) over the 32 lanes of its half.
+__device__ __forceinline__ float colsum16(float (&v)[16], int c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool up = c & 16;
+        const float send = up ? v[i] : v[i + 8], keep = up ? v[i + 8] : v[i];
+        v[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool up = c & 8;
+        const float send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
+        v[i] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool up = c & 4;
+        const float send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
+        v[i] = keep + __shfl_xor(send, 4, 64);
+    }
+    {
+        const bool up = c & 2;
+        const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+        v[0] = keep + __shfl_xor(send, 2, 64);
+    }
+    return v[0] + __shfl_xor(v[0], 1, 64);
+}
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -106,6 +136,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
             Ps[N + i] = p.ln_g[i];
             Ps[2 * N + i] = p.ln_b[i];
         }
+        if constexpr (EPI == EPI_LNB) Ps[N + i] = p.ln_g[i];
     }
 
     // staging of one X tile: thread -> XP pieces (row = f / PPR, piece = f % PPR), rows past the end clamped
@@ -152,6 +183,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
     const float ksd = p.drop.p > 0.f ? 1.f / (1.f - p.drop.p) : 1.f;
     const bool drop_on = p.drop.p > 0.f;
 
+    float col_g = 0.f, col_b = 0.f, col_c = 0.f;        // EPI_LNB: this lane's column sums (feature f0 + 16 h + colsum16's index)
     int buf = 0;
     for (; tile < ntiles; tile += nown, buf ^= 1) {
         const int tok = (int)(tile * TT) + c;
@@ -160,7 +192,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         const bool keep_y = p.y_rows < 0 || tokc < p.y_rows;
         __syncthreads();                                // X(tile) is in Xs[buf]; Red[buf] of two tiles ago has been consumed
         // epilogue operands of this tile (residual rows / previous output / gate reference): requested before the products
-        f32x4 res[EPI == EPI_LN || EPI == EPI_ACC ? RT : 1][4];
+        f32x4 res[EPI == EPI_LN || EPI == EPI_ACC || EPI == EPI_LNB ? RT : 1][4];
+        f32x4 rpre[EPI == EPI_LNB ? RT : 1][4];          // EPI_LNB: the pre-LayerNorm sums of the token
+        float2 lstat = float2{0.f, 1.f};
         u32x4 mref[EPI == EPI_MASK ? RT : 1][2];
         if constexpr (EPI == EPI_LN) {
             if (p.res_bf16) {
@@ -178,7 +212,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
                     for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(resp + 32 * rt + 4 * g);
             }
         }
-        if constexpr (EPI == EPI_ACC) {
+        if constexpr (EPI == EPI_LNB) {
+            static_assert(EPI != EPI_LNB || (RT == 1 && GROUPS == 1 && !F8), "LayerNorm-backward epilogue: 8 waves x 32 features");
+            const float* rp = p.res + (long)tokc * p.ldres + f0 + 16 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rpre[0][g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+            lstat = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)tokc);
+        }
+        if constexpr (EPI == EPI_ACC || EPI == EPI_LNB) {
             const float* yo = reinterpret_cast<const float*>(p.Y) + (long)tokc * p.ldy + gcol + f0 + 16 * h;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -221,7 +262,75 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
             store_x(buf ^ 1);
             if (tile + 2L * nown < ntiles) load_x(tile + 2L * nown);
         }
-        if constexpr (EPI != EPI_LN) {
+        if constexpr (EPI == EPI_LNB) {
+            // ---- += then LayerNorm backward: dy = Y + acc; dr = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) -------------------
+            const float mean = lstat.x, rstd = lstat.y;
+            const float nmr = -mean * rstd;              // xhat = r * rstd + nmr, recomputed where it is needed (no second 16-register copy)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(&Ps[N + f0 + 16 * h + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    acc[0][i] += res[0][g][j];              // dy
+                    const float gy = acc[0][i] * gw[j];
+                    s1 += gy;
+                    s2 += gy * (rpre[0][g][j] * rstd + nmr);
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            float* const red = Red + buf * NW * TT * 2;
+            if (h == 0) *reinterpret_cast<float2*>(&red[(wave * TT + c) * 2]) = float2{s1, s2};
+            __syncthreads();
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float2 v = *reinterpret_cast<const float2*>(&red[(w * TT + c) * 2]);
+                t1 += v.x;
+                t2 += v.y;
+            }
+            t1 *= 1.f / N;
+            t2 *= 1.f / N;
+            float* const drp = p.ln_y + (long)tokc * p.ldy + f0 + 16 * h;
+            __bf16* const dbp = reinterpret_cast<__bf16*>(p.lnb_dres) + (long)tokc * p.ldy + f0 + 16 * h;
+            const uint64_t dbase3 = (uint64_t)tokc * p.drop_ld + f0 + 16 * h;
+            float cc[16];
+            unsigned packed[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(&Ps[N + f0 + 16 * h + 4 * g]);
+                f32x4 v, vb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (acc[0][4 * g + j] * gw[j] - t1 - (rpre[0][g][j] * rstd + nmr) * t2) * rstd;
+                vb = v;
+                if (drop_on) {
+                    float f[4];
+                    drop_factor4(dkey, dbase3 + 4 * g, ksd, f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vb[j] = v[j] * f[j];
+                }
+                if (valid) *reinterpret_cast<f32x4*>(drp + 4 * g) = v;
+                packed[2 * g] = pack2(vb[0], vb[1]);
+                packed[2 * g + 1] = pack2(vb[2], vb[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cc[4 * g + j] = valid ? vb[j] : 0.f;
+            }
+            if (valid) {
+                *reinterpret_cast<u32x4*>(dbp) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+                *reinterpret_cast<u32x4*>(dbp + 8) = u32x4{packed[4], packed[5], packed[6], packed[7]};
+            }
+            col_c += colsum16(cc, c);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cc[4 * g + j] = valid ? acc[0][4 * g + j] * (rpre[0][g][j] * rstd + nmr) : 0.f;
+            col_g += colsum16(cc, c);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cc[i] = valid ? acc[0][i] : 0.f;
+            col_b += colsum16(cc, c);
+        } else if constexpr (EPI != EPI_LN) {
             // ---- plain epilogues: no cross-wave step, one barrier per tile ------------------------------------------
             const uint64_t dbase2 = (uint64_t)tokc * p.drop_ld + gcol + f0 + 16 * h;
 #pragma unroll
@@ -345,6 +454,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         }
         }       // EPI_LN
     }
+    if constexpr (EPI == EPI_LNB) {
+        if (!(c & 1)) {         // odd lanes hold the same totals
+            const int n = f0 + 16 * h + 8 * ((c >> 4) & 1) + 4 * ((c >> 3) & 1) + 2 * ((c >> 2) & 1) + ((c >> 1) & 1);
+            atomicAdd(p.lnb_dgamma + n, col_g);
+            atomicAdd(p.lnb_dbeta + n, col_b);
+            if (p.lnb_dbias) atomicAdd(p.lnb_dbias + n, col_c);
+        }
+    }
 }
 
 template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
@@ -408,7 +525,20 @@ int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
 //   6  y (bf16) = X W^T + b, N = 768 = 3 column groups of 256, K = 256, fp32 X   (packed QKV projection, forward)
 //   7  as 5 (K = 768) as 2 column groups of 128                          (dx += dqkv Win)
 //   8 / 9  as 2 / 6 with bf16 X (the LayerNorm outputs stored in bf16: engine.hip "xst")
+//   10 as 1 followed by the LayerNorm backward of the sum (EPI_LNB: dr, masked bf16 branch gradient, gamma / beta / bias column sums)
 int wst_kind(const TlinP& p) {
+    if (p.lnb_dres) {       // += then LayerNorm backward (dx1 = dr2 + dh W1 followed by LN1 backward)
+        static const bool off = getenv("GG_NO_WST_LNB") != nullptr;
+        if (off || p.fp8 || p.film_g || p.y_row_group || p.M < 1 || !p.accumulate || p.mask_ref || p.act_relu || p.y_bf16 || !p.x_bf16 || p.bias ||
+            p.res_bf16 || p.ln_y_bf16)
+            return 0;
+        if (p.N != 256 || p.K != 512 || !p.res || !p.ln_g || !p.ln_y || !p.ln_stats || !p.lnb_dgamma || !p.lnb_dbeta) return 0;
+        if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || !al16(p.res) || !al16(p.ln_y) || !al16(p.lnb_dres) || p.ldw % 8 || p.ldx % 8 || p.ldy % 8 ||
+            p.ldres % 4 || p.res_rows < p.M)
+            return 0;
+        if (p.drop.p > 0.f && (p.drop_ld % 2)) return 0;
+        return 10;
+    }
     if (p.fp8 || p.ln_g || p.res || p.film_g || p.y_row_group || p.M < 1) return 0;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 8 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
     if (p.drop.p > 0.f && p.drop_ld % 2) return 0;
@@ -470,6 +600,7 @@ int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         case 7: return launch<4, 1, 48, true, EPI_ACC, false, 2>(p, st, ev0, ev1);
         case 8: return launch<8, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
         case 9: return launch<4, 2, 16, true, EPI_ACT, false, 3>(p, st, ev0, ev1);
+        case 10: return launch<8, 1, 32, true, EPI_LNB>(p, st, ev0, ev1);
     }
     set_error("wst_other: no instantiation for this call");
     return -2;

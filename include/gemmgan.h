@@ -203,6 +203,7 @@ int gg_set_precision(gg_engine* e, int precision);    /* GG_PREC_* ; may be swit
 int gg_set_flash(gg_engine* e, int on);               /* fused attention kernels in bf16 mode (default on) */
 int gg_set_wgrad(gg_engine* e, int on);               /* long-reduction weight-gradient kernel in bf16 mode (default on) */
 int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
+int gg_set_lnb_fused(gg_engine* e, int on);           /* dx1 += and LayerNorm-1 backward in one kernel, bf16 mode at E = 256 (default on) */
 int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the encoder's LayerNorm outputs, bf16 mode at E = 256 (default on) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
@@ -241,6 +242,8 @@ typedef struct gg_test_linear_args {     /* Y = epi(X W^T): the encoder-layer Li
     const float* res; int64_t ldres; int64_t res_rows;           /* + res[row % res_rows]                                      */
     const float* ln_g; const float* ln_b; float* ln_y; float* ln_stats;                  /* LayerNorm of the sum (eps 1e-5)    */
     int32_t res_bf16, ln_y_bf16;                                 /* route 0: `res` / `ln_y` are bf16 arrays (same strides, elements) */
+    void* lnb_dres; float* lnb_dgamma; float* lnb_dbeta; float* lnb_dbias;   /* route 0, accumulate: += then LayerNorm backward (wst.hip EPI_LNB):
+                          Y = dr_in (read), res = pre-LN sums, ln_stats (read), ln_g; ln_y = dr out, lnb_dres = masked branch gradient (bf16) */
     void* w_parts;     /* routes 2 / 3: scratch for the pre-split weights, route * N * K bf16 elements                                  */
     int32_t route;     /* 0: as the engine routes it (weight-stationary kernel when one takes the shape), 1: token-on-lane kernels only,
                           2 / 3: the split-operand Linear of GG_PREC_BF16X3 with 2 (hi, lo: three products, the backward form) /

@@ -639,6 +639,62 @@ def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
     check("fused bias gradient", dbias_d, dres.sum(0), False)        # column sums of the fp32 values, before the bf16 store
 
 
+@pytest.mark.parametrize("M,drop_on", [(8 * 257, True), (70000 + 5, True), (3 * 257, False)])
+def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, drop_on):
+    """wst_ln_kernel<8,1,32,true,EPI_LNB> (csrc/wst.hip): dy = dr_in + dh W1 (K = 512, bf16 dh) followed, in the same launch, by the
+    backward of LayerNorm-1: dr (fp32), the dropout-masked branch gradient (bf16) and the gamma / beta / out-proj-bias column sums
+    (reduce-scatter butterfly over the token lanes, one atomic per feature and workgroup).  M = 70 005: several tiles per persistent
+    workgroup and a ragged last tile (clamped lanes must not reach the column sums)."""
+    lib = L.load()
+    E, F = 256, 512
+    g = torch.Generator().manual_seed(M + 9)
+    dh, W = bf(rnd(g, M, F, scale=0.1)), bf(rnd(g, E, F, scale=0.05))
+    dr_in, r, gam = rnd(g, M, E, scale=0.1), rnd(g, M, E), 1 + rnd(g, E, scale=0.1)
+    mu = r.double().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((r.double() - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+    stats = torch.cat([mu, rstd], 1).float()
+    drop = (0.1, 5, 1011, 2) if drop_on else (0.0, 0, 0, 0)
+    d = lambda t, dt=torch.float32: t.to(DEV, dt).contiguous()
+    X_d, W_d, Y_d, r_d, g_d, st_d = d(dh, torch.bfloat16), d(W, torch.bfloat16), d(dr_in), d(r), d(gam), d(stats)
+    dr_d = torch.full((M, E), float("nan"), device=DEV)
+    dres_d = torch.full((M, E), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dg_d, db_d, dbias_d = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+    a = L.GGTestLinear()
+    a.X, a.ldx, a.M, a.x_bf16 = X_d.data_ptr(), F, M, 1
+    a.W, a.ldw = W_d.data_ptr(), F
+    a.Y, a.ldy, a.y_bf16, a.y_rows = Y_d.data_ptr(), E, 0, -1
+    a.N, a.K, a.accumulate = E, F, 1
+    a.res, a.ldres, a.res_rows = r_d.data_ptr(), E, M
+    a.ln_g, a.ln_y, a.ln_stats = g_d.data_ptr(), dr_d.data_ptr(), st_d.data_ptr()
+    a.lnb_dres, a.lnb_dgamma, a.lnb_dbeta, a.lnb_dbias = dres_d.data_ptr(), dg_d.data_ptr(), db_d.data_ptr(), dbias_d.data_ptr()
+    a.drop_p, a.drop_seed, a.drop_site, a.drop_call = drop
+    a.drop_ld = E
+    a.route = 0
+    cls = C.c_int32(-1)
+    Y_before = Y_d.clone()
+    L.check(lib.gg_test_linear(C.byref(a), C.byref(cls), stream()))
+    torch.cuda.synchronize()
+    assert cls.value == 50, cls.value                          # the fused kernel ran
+    assert torch.equal(Y_d, Y_before)                          # dr_in is read, not rewritten
+    dy = dr_in.double() + dh.double() @ W.double().T
+    mu, rstd = stats[:, :1].double(), stats[:, 1:].double()
+    xh = (r.double() - mu) * rstd
+    dyg = dy * gam.double()
+    dr = rstd * (dyg - dyg.mean(-1, keepdim=True) - xh * (dyg * xh).mean(-1, keepdim=True))
+    keep, ks = torch.ones(M, E, dtype=torch.float64), 1.0
+    if drop_on:
+        k0, thr = drop_key(*drop)
+        keep = torch.from_numpy(drop_keep(k0, thr, np.arange(M * E, dtype=np.int64)).reshape(M, E)).double()
+        ks = keep_scale(drop[0])
+    dres = dr * keep * ks
+    diag(f"== += then LayerNorm backward (M = {M}, dropout {drop_on})")
+    check("dr", dr_d, dr, False)
+    check("masked branch gradient", dres_d, dres, True)
+    check("dgamma", dg_d, (dy * xh).sum(0), False)
+    check("dbeta", db_d, dy.sum(0), False)
+    check("fused bias gradient", dbias_d, dres.sum(0), False)
+
+
 # ---- fused feed-forward block ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,keep_rows,drop_on", [(8 * 257, -1, True), (8 * 257, 3 * 257, True), (5 * 257 + 3, 0, False), (70000, 1000, True)])
 def test_fused_feed_forward_block_equals_the_fp64_result(M, keep_rows, drop_on):
