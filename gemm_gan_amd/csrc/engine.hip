@@ -88,6 +88,7 @@ struct CondActs {
     float drop = 0.f;
     bool flash = false;
     bool bst = false;          // qkv / ctx / h (and their gradients) stored as bf16 in this pass
+    bool rst = false;          // the pre-LayerNorm sums r1 / r2 (kept for the backward pass) stored as bf16 in this pass
     bool xst = false;          // the LayerNorm outputs x1 (every layer) and x2 (all but the last layer) stored as bf16 in this pass
     float *gbpre, *gb, *tok, *x0, *xrep, *tokrep;
     float *pe_h = nullptr, *pe_y = nullptr, *pe_st = nullptr, *pe_zero = nullptr;     // Linear->ReLU->LayerNorm patch encoder (img variant)
@@ -229,6 +230,7 @@ struct gg_engine {
     int n_str_cls = 0;
     std::string str_cls_name[14];
     int lnb_on = getenv("GG_NO_WST_LNB") == nullptr;      // dx1 += and LN1 backward in one weight-stationary kernel (production width, bf16 mode)
+    int rstore_on = getenv("GG_NO_RSTORE") == nullptr;    // ... and of the pre-LayerNorm sums kept for the backward pass
     int xstore_on = getenv("GG_NO_XSTORE") == nullptr;   // bf16 storage of the encoder's LayerNorm outputs (production width, bf16 mode)
 };
 
@@ -857,6 +859,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     static const bool wst_env = getenv("GG_NO_WST") == nullptr && getenv("GG_NO_WST2") == nullptr && getenv("GG_NO_WST_QKV") == nullptr;
     const bool xst = bst && e->xstore_on && wst_env && !e->fp8_fwd && E == 256 && F == 2 * E;
     a.xst = xst;
+    // ... and so are the pre-LayerNorm sums the backward pass re-reads (xhat = (r - mean) * rstd with the fp32 statistics of the
+    // unrounded sum: a 2^-9 perturbation of xhat, the same order as the bf16 operands of every product around it)
+    const bool rst = xst && e->rstore_on;
+    a.rst = rst;
     // The replicas differ only by their dropout draws, and nothing is dropped before the first attention: the layer-0
     // input x0 and its QKV projection are the same for all of them.  With the fused kernels (row / sample indices taken
     // modulo the un-replicated size) neither the R-fold copy of x0 nor R-1 of the R projections exist.
@@ -928,7 +934,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             t.Y = L.r1; t.ldy = E; t.N = E; t.K = E; t.drop = dkey(e, a, n.role, l, 1); t.drop_ld = E;
             t.res = x_in; t.ldres = E; t.res_rows = (share0 && l == 0) ? (long)B * S : RB * S; t.y_rows = keep_rows;
             t.ln_g = w + lp.n1w; t.ln_b = w + lp.n1b; t.ln_y = L.x1; t.ln_stats = L.st1; t.x_bf16 = bst;
-            t.res_bf16 = xst && l > 0; t.ln_y_bf16 = xst;
+            t.res_bf16 = xst && l > 0; t.ln_y_bf16 = xst; t.y_bf16 = rst;
             if (bst) maybe_fp8(e, n, t, lp.sa.ow);
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, {
@@ -970,7 +976,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
                 t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
                 t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
-                t.res_bf16 = xst; t.ln_y_bf16 = xst && l + 1 < e->nl;
+                t.res_bf16 = xst; t.ln_y_bf16 = xst && l + 1 < e->nl; t.y_bf16 = rst;
                 if (bst) maybe_fp8(e, n, t, lp.l2w);
                 if (bst) TLIN_MUST(t);
                 else TLIN_OR(t, {
@@ -1264,7 +1270,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         {   // reads dy and the saved pre-LN sum (fp32), writes dr (fp32) and the masked branch gradient (bf16 when stored so)
             ProfScope ps(c, "ln_bwd_v4_k", 16.0 * RB * S * E, (double)RB * S * (E * (12.0 + (bst ? 2.0 : 4.0)) + 8.0));
             KL(k_layernorm_bwd(dx, L.r2, L.st2, w + lp.n2w, e->sdr, e->sdres, g + lp.n2w, g + lp.n2b, g + lp.l2b, RB * S, E,
-                               dkey(e, a, n.role, l, 3), c.st, bst));
+                               dkey(e, a, n.role, l, 3), c.st, bst | (a.rst ? 2 : 0)));
         }
         // FFN: f = h W2^T + b2 ; h = drop(relu(x1 W1^T + b1))   (db2 = column sums of df: fused above)
         {
@@ -1302,7 +1308,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             t.Y = e->sdr; t.ldy = E; t.N = E; t.K = F; t.accumulate = 1; t.x_bf16 = bst;
             if (bst && e->lnb_on) {
                 TlinP u = t;
-                u.res = L.r1; u.ldres = E; u.res_rows = RB * S; u.ln_stats = L.st1; u.ln_g = w + lp.n1w; u.ln_y = dx;
+                u.res = L.r1; u.ldres = E; u.res_rows = RB * S; u.res_bf16 = a.rst; u.ln_stats = L.st1; u.ln_g = w + lp.n1w; u.ln_y = dx;
                 u.lnb_dres = reinterpret_cast<__bf16*>(e->sdres) + RB * S * E;
                 u.lnb_dgamma = g + lp.n1w; u.lnb_dbeta = g + lp.n1b; u.lnb_dbias = g + lp.sa.ob;
                 u.drop = dkey(e, a, n.role, l, 1); u.drop_ld = E;
@@ -1322,7 +1328,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             GG_TRY(side_wait(c, 0));
             ProfScope ps(c, "ln_bwd_v4_k", 16.0 * RB * S * E, (double)RB * S * (E * (12.0 + (bst ? 2.0 : 4.0)) + 8.0));
             KL(k_layernorm_bwd(e->sdr, L.r1, L.st1, w + lp.n1w, dx, e->sdres, g + lp.n1w, g + lp.n1b, g + lp.sa.ob, RB * S, E,
-                               dkey(e, a, n.role, l, 1), c.st, bst));
+                               dkey(e, a, n.role, l, 1), c.st, bst | (a.rst ? 2 : 0)));
         }
         // self attention out-proj   (d(out_proj.bias) fused above)
         {
@@ -2146,7 +2152,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2314,7 +2320,8 @@ int gg_set_lnb_fused(gg_engine* e, int on) {
 }
 int gg_set_xstore(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
-    e->xstore_on = on != 0;
+    e->xstore_on = on & 1;
+    e->rstore_on = (on & 1) && !(on & 2);        // bit 1: keep the pre-LayerNorm sums in fp32
     return 0;
 }
 int gg_debug_buffer_is_bf16(gg_engine* e, const char* name) {
@@ -2325,6 +2332,7 @@ int gg_debug_buffer_is_bf16(gg_engine* e, const char* name) {
         const std::string k = s.substr(5);
         if (a.bst && (k == "qkv" || k == "ctx" || k == "h")) return 1;
         if (a.xst && (k == "x1" || (k == "x2" && s[3] - '0' + 1 < e->nl))) return 1;
+        if (a.rst && (k == "r1" || k == "r2")) return 1;
     }
     return 0;
 }

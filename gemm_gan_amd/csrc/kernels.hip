@@ -432,7 +432,7 @@ __device__ __forceinline__ unsigned pack2_k(float a, float b) {
     bf16x2_k v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
 }
-template <int NV>
+template <int NV, bool RB16 = false>
 __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float* r, const float* stats, const float* g,
                                                     float* dr, void* dres, int dres_bf16, float* dgamma, float* dbeta,
                                                     float* dbias, long rows, int E, DropKey drop_in) {
@@ -459,7 +459,13 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
         for (int j = 0; j < NV; ++j) {
             const int c = min(4 * lane + 256 * j, E - 4);
             nd[j] = *reinterpret_cast<const f32x4*>(dy + rc * E + c);
-            nr[j] = *reinterpret_cast<const f32x4*>(r + rc * E + c);
+            if constexpr (RB16) {          // pre-LayerNorm sums stored in bf16 (engine.hip "rst")
+                const u32x2_k w = *reinterpret_cast<const u32x2_k*>(reinterpret_cast<const __bf16*>(r) + rc * E + c);
+                nr[j] = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                              __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+            } else {
+                nr[j] = *reinterpret_cast<const f32x4*>(r + rc * E + c);
+            }
         }
     };
     if (row < rows) request(row);
@@ -535,7 +541,8 @@ __global__ __launch_bounds__(TPB) void ln_bwd_v4_k(const float* dy, const float*
 }
 
 int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out,
-                    float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st, int dres_bf16) {
+                    float* dgamma, float* dbeta, float* dbias, long rows, int E, DropKey drop, hipStream_t st, int dres_flags) {
+    const int dres_bf16 = dres_flags & 1, r_bf16 = (dres_flags >> 1) & 1;        // bit 0: bf16 branch-gradient output, bit 1: bf16 r
     // Rows per wave: the kernel ends with 3 x E atomic adds per workgroup into the SAME E addresses (gamma / beta / bias
     // gradients), which serialise per address at the memory side - at 16 rows per wave (2 056 workgroups for the 131 584
     // rows of a backward pass) that tail was a fifth of the kernel (122 us); 32 rows: 99 us (4.4 TB/s), 64 rows: too few
@@ -546,13 +553,17 @@ int k_layernorm_bwd(const float* dy, const float* r, const float* stats, const f
                       reinterpret_cast<uintptr_t>(dr) | reinterpret_cast<uintptr_t>(dres_out)) & 15) == 0;
     if (E % 4 == 0 && E <= 1024 && al) {
 #define GG_LN_BWD4(NV) ln_bwd_v4_k<NV><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dres_bf16, dgamma, dbeta, dbias, rows, E, drop)
+        if (r_bf16) {
+            GG_REQUIRE(E == 256, "bf16 pre-LayerNorm sums: production width only");
+            ln_bwd_v4_k<1, true><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, dres_out, dres_bf16, dgamma, dbeta, dbias, rows, E, drop);
+        } else
         if (E <= 256) GG_LN_BWD4(1);
         else if (E <= 512) GG_LN_BWD4(2);
         else GG_LN_BWD4(4);
 #undef GG_LN_BWD4
         GG_LAUNCH_CHECK();
     }
-    GG_REQUIRE(!dres_bf16, "bf16 branch-gradient output needs the vectorised LayerNorm backward (E % 4 == 0, aligned)");
+    GG_REQUIRE(!dres_bf16 && !r_bf16, "bf16 branch-gradient output / bf16 sums need the vectorised LayerNorm backward (E % 4 == 0, aligned)");
 #define GG_LN_BWD(NJ) ln_bwd_k<NJ><<<nb, TPB, 0, st>>>(dy, r, stats, g, dr, reinterpret_cast<float*>(dres_out), dgamma, dbeta, dbias, rows, E, drop)
     if (E <= 64) GG_LN_BWD(1);
     else if (E <= 128) GG_LN_BWD(2);

@@ -1004,7 +1004,7 @@ bool tlin_supported(const TlinP& p) {
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
     if (p.y_bf16 && p.accumulate) return false;
-    if ((p.res_bf16 || p.ln_y_bf16) && !(wst_routed(p) && wst_ln_supported(p))) return false;      // bf16 residual / LN output: wst.hip only
+    if (p.ln_g && (p.res_bf16 || p.ln_y_bf16 || p.y_bf16)) return wst_routed(p) && wst_ln_supported(p);      // bf16 residual / LN output / pre-LN sum: wst.hip only
     if (p.drop.p > 0.f && p.drop_ld % 2) return false;      // the epilogues hash element PAIRS (drop_rng.h)
     if (!needs_resident(p)) return (size_t)p.N * 4 <= 64 * 1024;     // bias vector in LDS
     if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue

@@ -214,9 +214,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         }
         if constexpr (EPI == EPI_LNB) {
             static_assert(EPI != EPI_LNB || (RT == 1 && GROUPS == 1 && !F8), "LayerNorm-backward epilogue: 8 waves x 32 features");
-            const float* rp = p.res + (long)tokc * p.ldres + f0 + 16 * h;
+            if (p.res_bf16) {
+                const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + (long)tokc * p.ldres + f0 + 16 * h;
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(rp), w1 = *reinterpret_cast<const u32x4*>(rp + 8);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rpre[0][g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned a = g < 2 ? w0[2 * (g & 1)] : w1[2 * (g & 1)], b = g < 2 ? w0[2 * (g & 1) + 1] : w1[2 * (g & 1) + 1];
+                    rpre[0][g] = f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u),
+                                       __builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
+                }
+            } else {
+                const float* rp = p.res + (long)tokc * p.ldres + f0 + 16 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rpre[0][g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+            }
             lstat = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)tokc);
         }
         if constexpr (EPI == EPI_ACC || EPI == EPI_LNB) {
@@ -379,9 +390,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         // ---- epilogue 1: bias, dropout, residual; r stored; this wave's share of the row sums ------------------------
         float s1 = 0.f, s2 = 0.f;
         float* const yb = reinterpret_cast<float*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h;
+        __bf16* const ybh = reinterpret_cast<__bf16*>(p.Y) + (long)tokc * p.ldy + f0 + 16 * h;
         const uint64_t dbase = (uint64_t)tokc * p.drop_ld + f0 + 16 * h;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
+            unsigned rpk[8];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ps[f0 + 32 * rt + 16 * h + 4 * g]);
@@ -401,13 +414,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
                 } else {
                     v += res[rt][g];
                 }
-                if (valid && keep_y) *reinterpret_cast<f32x4*>(yb + 32 * rt + 4 * g) = v;
+                if (!p.y_bf16 && valid && keep_y) *reinterpret_cast<f32x4*>(yb + 32 * rt + 4 * g) = v;
+                rpk[2 * g] = pack2(v[0], v[1]);
+                rpk[2 * g + 1] = pack2(v[2], v[3]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[rt][4 * g + j] = v[j];
                     s1 += v[j];
                     s2 += v[j] * v[j];
                 }
+            }
+            if (p.y_bf16 && valid && keep_y) {          // the pre-LayerNorm sum kept for the backward pass in bf16 (statistics from the fp32 values)
+                *reinterpret_cast<u32x4*>(ybh + 32 * rt) = u32x4{rpk[0], rpk[1], rpk[2], rpk[3]};
+                *reinterpret_cast<u32x4*>(ybh + 32 * rt + 8) = u32x4{rpk[4], rpk[5], rpk[6], rpk[7]};
             }
         }
         s1 += __shfl_xor(s1, 32, 64);
@@ -503,9 +522,9 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 bool wst_ln_supported(const TlinP& p) {
     if (!p.ln_g || !p.ln_b || !p.ln_y || !p.ln_stats || !p.res || !p.x_bf16 || p.fp8) return false;
     if (p.N != 256 || (p.K != 256 && p.K != 512) || p.M < 1) return false;
-    if (p.accumulate || p.mask_ref || p.act_relu || p.y_bf16 || p.film_g || p.y_row_group) return false;
+    if (p.accumulate || p.mask_ref || p.act_relu || p.film_g || p.y_row_group) return false;
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || !al16(p.res) || !al16(p.ln_y) || p.ldx % 8 || p.ldw % 8 || p.ldy % 4 || p.ldres % 4) return false;
-    if ((p.res_bf16 && p.ldres % 8) || (p.ln_y_bf16 && p.ldy % 8)) return false;
+    if ((p.res_bf16 && p.ldres % 8) || ((p.ln_y_bf16 || p.y_bf16) && p.ldy % 8)) return false;
     if (p.drop.p > 0.f && p.drop_ld % 2) return false;
     return true;
 }
@@ -530,7 +549,7 @@ int wst_kind(const TlinP& p) {
     if (p.lnb_dres) {       // += then LayerNorm backward (dx1 = dr2 + dh W1 followed by LN1 backward)
         static const bool off = getenv("GG_NO_WST_LNB") != nullptr;
         if (off || p.fp8 || p.film_g || p.y_row_group || p.M < 1 || !p.accumulate || p.mask_ref || p.act_relu || p.y_bf16 || !p.x_bf16 || p.bias ||
-            p.res_bf16 || p.ln_y_bf16)
+            p.ln_y_bf16 || (p.res_bf16 && p.ldres % 8))
             return 0;
         if (p.N != 256 || p.K != 512 || !p.res || !p.ln_g || !p.ln_y || !p.ln_stats || !p.lnb_dgamma || !p.lnb_dbeta) return 0;
         if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || !al16(p.res) || !al16(p.ln_y) || !al16(p.lnb_dres) || p.ldw % 8 || p.ldx % 8 || p.ldy % 8 ||

@@ -204,7 +204,8 @@ int gg_set_flash(gg_engine* e, int on);               /* fused attention kernels
 int gg_set_wgrad(gg_engine* e, int on);               /* long-reduction weight-gradient kernel in bf16 mode (default on) */
 int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
 int gg_set_lnb_fused(gg_engine* e, int on);           /* dx1 += and LayerNorm-1 backward in one kernel, bf16 mode at E = 256 (default on) */
-int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the encoder's LayerNorm outputs, bf16 mode at E = 256 (default on) */
+int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the encoder's LayerNorm outputs and of the pre-LayerNorm sums kept
+                                                          for the backward pass, bf16 mode at E = 256 (default 1; 0 off; 3 = outputs only) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
 int gg_set_ffn_fused(gg_engine* e, int on);           /* fused feed-forward block (one launch per layer) in bf16 mode at E = 256 (default off: measured slower than the two launches) */
@@ -276,7 +277,8 @@ int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int ma
                     int nh, void* stream);
 int gg_test_sqx_bwd(const float* dxbar, const float* qt, const float* xbar, const float* x, const float* probs, float* dx, float* dqt,
                     int N, int S, int E, int nh, void* stream);
-/* LayerNorm backward with the dropout-masked branch gradient (fp32 or bf16) and the fused bias / gamma / beta column sums */
+/* LayerNorm backward with the dropout-masked branch gradient (fp32 or bf16) and the fused bias / gamma / beta column sums;
+ * dres_bf16: bit 0 = bf16 branch-gradient output, bit 1 = r is a bf16 array (E = 256 only) */
 int gg_test_ln_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out, float* dgamma,
                    float* dbeta, float* dbias, int64_t rows, int E, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                    uint32_t drop_call, int dres_bf16, void* stream);

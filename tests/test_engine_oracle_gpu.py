@@ -455,7 +455,7 @@ def test_bf16_storage_of_the_layernorm_outputs_changes_only_the_residual_roundin
     names = ["D.L0.x1", "D.L0.x2", "D.L1.x1", "D.L1.x2", "D.c"]
     out = {}
     for on in (False, True):
-        eng.set_xstore(on)
+        eng.set_xstore(on)          # (the pre-LayerNorm sums r1 / r2 follow: bf16 too)
         eng.set_seed(5)
         eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
         out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(),

@@ -260,6 +260,13 @@ LINEAR_CASES = {
     "ffn2_bf16_residual_bf16_output": (lambda g: dict(X=bf(rnd(g, M_, F_).clamp_min(0)), x_bf16=True, W=bf(rnd(g, E_, F_, scale=0.05)), N=E_, K=F_,
                                                       bias=rnd(g, E_, scale=0.1), drop=(0.1, 7, 1013, 6), res=bf(rnd(g, M_, E_)), res_bf16=True,
                                                       ln_y_bf16=True, y_rows=4 * 257, ln=(1 + rnd(g, E_, scale=0.1), rnd(g, E_, scale=0.1))), 33),
+    "out_proj_bf16_everything": (lambda g: dict(X=bf(rnd(g, M_, E_)), x_bf16=True, W=bf(rnd(g, E_, E_, scale=0.06)), N=E_, K=E_,
+                                                bias=rnd(g, E_, scale=0.1), drop=(0.1, 7, 1011, 7), res=bf(rnd(g, M_, E_)), res_bf16=True,
+                                                ln_y_bf16=True, y_bf16=True, y_rows=5 * 257,
+                                                ln=(1 + rnd(g, E_, scale=0.1), rnd(g, E_, scale=0.1))), 32),
+    "ffn2_bf16_everything": (lambda g: dict(X=bf(rnd(g, M_, F_).clamp_min(0)), x_bf16=True, W=bf(rnd(g, E_, F_, scale=0.05)), N=E_, K=F_,
+                                            bias=rnd(g, E_, scale=0.1), drop=(0.1, 7, 1013, 7), res=bf(rnd(g, M_, E_)), res_bf16=True,
+                                            ln_y_bf16=True, y_bf16=True, ln=(1 + rnd(g, E_, scale=0.1), rnd(g, E_, scale=0.1))), 33),
     "patch_encoder_film_cls_rows": (lambda g: dict(X=rnd(g, 8 * 256, 1024), W=bf(rnd(g, E_, 1024, scale=0.03)), N=E_, K=1024,
                                                    bias=rnd(g, E_, scale=0.1), y_row_group=256,
                                                    film=(torch.tanh(rnd(g, 8, 1024)), rnd(g, 8, 1024).clamp(-5, 5), 256)), 1),
@@ -291,7 +298,7 @@ def _linear_case(name, route):
     if kw.get("y_rows", -1) >= 0:
         yr = kw["y_rows"]
         assert torch.isnan(yg[yr:]).all(), "pre-LayerNorm sums of forward-only rows must not be stored"
-        check("pre-LN sum (stored rows)", yg[:yr], yw[:yr], False)
+        check("pre-LN sum (stored rows)", yg[:yr], yw[:yr], bool(kw.get("y_bf16")))
     else:
         check("Y", yg, yw, bool(kw.get("y_bf16")))
     if "ln_y" in want:
@@ -309,7 +316,7 @@ def test_linear_kernels_of_the_hot_path_equal_the_fp64_product(name):
     _linear_case(name, 0)
 
 
-XSTORE_CASES = [n for n in LINEAR_CASES if "bf16_residual" in n or "bf16_output" in n]        # weight-stationary kernels only
+XSTORE_CASES = [n for n in LINEAR_CASES if "bf16_residual" in n or "bf16_output" in n or "bf16_everything" in n]        # weight-stationary kernels only
 
 
 @pytest.mark.parametrize("name", [n for n in LINEAR_CASES if n != "patch_encoder_film_cls_rows" and n not in XSTORE_CASES])
@@ -602,8 +609,9 @@ def test_single_query_sweeps_equal_the_fp64_result(S, E, nh):
 
 
 # ---- LayerNorm backward with the fused column sums -----------------------------------------------------------------------------
-@pytest.mark.parametrize("dres_bf16,drop_on", [(1, True), (0, False)])
-def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
+@pytest.mark.parametrize("dres_bf16,drop_on,r_bf16", [(1, True, False), (0, False, False), (1, True, True)])
+def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on, r_bf16):
+    """r_bf16: the pre-LayerNorm sums as the engine keeps them at the production width (bf16 array, statistics of the unrounded sums)."""
     lib = L.load()
     rows, E = 8 * 257, 256
     g = torch.Generator().manual_seed(3)
@@ -614,11 +622,14 @@ def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
     drop = (0.1, 5, 1013, 2) if drop_on else (0.0, 0, 0, 0)
     d = lambda t: t.to(DEV).contiguous()
     r_d, dy_d, g_d, st_d = d(r), d(dy), d(gam), d(stats)
+    if r_bf16:
+        r_d = r_d.to(torch.bfloat16)
+        r = r_d.float().cpu()              # the values the kernel reads (the statistics above stay those of the unrounded sums)
     dr_d = torch.empty(rows, E, device=DEV)
     dres_d = torch.empty(rows, E, dtype=torch.bfloat16 if dres_bf16 else torch.float32, device=DEV)
     dg_d, db_d, dbias_d = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
     L.check(lib.gg_test_ln_bwd(P(dy_d), P(r_d), P(st_d), P(g_d), P(dr_d), P(dres_d), P(dg_d), P(db_d), P(dbias_d), rows, E,
-                               C.c_float(drop[0]), drop[1], drop[2], drop[3], dres_bf16, stream()))
+                               C.c_float(drop[0]), drop[1], drop[2], drop[3], dres_bf16 | (2 if r_bf16 else 0), stream()))
     torch.cuda.synchronize()
     mu, rstd = stats[:, :1].double(), stats[:, 1:].double()
     xh = (r.double() - mu) * rstd
@@ -639,8 +650,8 @@ def test_layernorm_backward_with_fused_column_sums(dres_bf16, drop_on):
     check("fused bias gradient", dbias_d, dres.sum(0), False)        # column sums of the fp32 values, before the bf16 store
 
 
-@pytest.mark.parametrize("M,drop_on", [(8 * 257, True), (70000 + 5, True), (3 * 257, False)])
-def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, drop_on):
+@pytest.mark.parametrize("M,drop_on,r_bf16", [(8 * 257, True, False), (70000 + 5, True, True), (3 * 257, False, True)])
+def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, drop_on, r_bf16):
     """wst_ln_kernel<8,1,32,true,EPI_LNB> (csrc/wst.hip): dy = dr_in + dh W1 (K = 512, bf16 dh) followed, in the same launch, by the
     backward of LayerNorm-1: dr (fp32), the dropout-masked branch gradient (bf16) and the gamma / beta / out-proj-bias column sums
     (reduce-scatter butterfly over the token lanes, one atomic per feature and workgroup).  M = 70 005: several tiles per persistent
@@ -656,6 +667,9 @@ def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, dro
     drop = (0.1, 5, 1011, 2) if drop_on else (0.0, 0, 0, 0)
     d = lambda t, dt=torch.float32: t.to(DEV, dt).contiguous()
     X_d, W_d, Y_d, r_d, g_d, st_d = d(dh, torch.bfloat16), d(W, torch.bfloat16), d(dr_in), d(r), d(gam), d(stats)
+    if r_bf16:          # pre-LayerNorm sums as the engine keeps them (bf16), statistics of the unrounded sums
+        r_d = r_d.to(torch.bfloat16)
+        r = r_d.float().cpu()
     dr_d = torch.full((M, E), float("nan"), device=DEV)
     dres_d = torch.full((M, E), float("nan"), dtype=torch.bfloat16, device=DEV)
     dg_d, db_d, dbias_d = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
@@ -664,7 +678,7 @@ def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, dro
     a.W, a.ldw = W_d.data_ptr(), F
     a.Y, a.ldy, a.y_bf16, a.y_rows = Y_d.data_ptr(), E, 0, -1
     a.N, a.K, a.accumulate = E, F, 1
-    a.res, a.ldres, a.res_rows = r_d.data_ptr(), E, M
+    a.res, a.ldres, a.res_rows, a.res_bf16 = r_d.data_ptr(), E, M, int(r_bf16)
     a.ln_g, a.ln_y, a.ln_stats = g_d.data_ptr(), dr_d.data_ptr(), st_d.data_ptr()
     a.lnb_dres, a.lnb_dgamma, a.lnb_dbeta, a.lnb_dbias = dres_d.data_ptr(), dg_d.data_ptr(), db_d.data_ptr(), dbias_d.data_ptr()
     a.drop_p, a.drop_seed, a.drop_site, a.drop_call = drop
