@@ -721,14 +721,15 @@ int try_tlin(Ctx& c, const TlinP& p) {
         if (id == 0 && e->n_str_cls < 12) {      // ids stay below 30: the class mask travels shifted by one in an int
             id = 18 + e->n_str_cls++;
             char nm[64];
-            static const char* extra[19] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
+            static const char* extra[21] = {"wst_ln_kernel<4,2,16,true,0>", "wst_ln_kernel<8,1,32,true,0>", "wst_ln_kernel<8,1,32,true,1>",
                                             "wst_ln_kernel<8,2,16,false,2>", "wst_ln_kernel<8,2,16,true,3>", "wst_ln_kernel<4,2,16,true,2>",
                                             "wst_ln_kernel<8,1,48,true,1>",
                                             "tlin_res16_kernel<8,256,true,1,true>", "tlin_str_kernel<256,false,true,0,true>",
                                             "tlin_str_kernel<256,false,true,1,true>", "wst_ln_kernel<4,2,16,true,0,true>",
                                             "wst_ln_kernel<8,1,32,true,0,true>", "wst_ln_kernel<8,2,16,false,2,true>",
                                             "wst_ln_kernel<8,3,16,false,2,true>", "wst_ln_kernel<4,2,16,false,2,false,3>", "wst_ln_kernel<4,1,48,true,1,false,2>",
-                                            "wst_ln_kernel<8,2,16,true,2>", "wst_ln_kernel<4,2,16,true,2,false,3>", "wst_ln_kernel<8,1,32,true,4>"};
+                                            "wst_ln_kernel<8,2,16,true,2>", "wst_ln_kernel<4,2,16,true,2,false,3>", "wst_ln_kernel<8,1,32,true,4>",
+                                            "wst_ln_kernel<8,2,16,true,2,true>", "wst_ln_kernel<8,3,16,true,2,true>"};
             if (kc >= 32) snprintf(nm, sizeof nm, "%s", extra[kc - 32]);
             else
             snprintf(nm, sizeof nm, "tlin_str_kernel<256,%s,%s,%d>", ((kc - 16) & 1) ? "true" : "false", ((kc - 16) & 2) ? "true" : "false", (kc - 16) >> 2);
@@ -857,7 +858,7 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // pre-LayerNorm sums r1 / r2 and the statistics stay fp32 (LayerNorm backward), and so does the last layer's output
     // (cross-attention and CLS read it as fp32).
     static const bool wst_env = getenv("GG_NO_WST") == nullptr && getenv("GG_NO_WST2") == nullptr && getenv("GG_NO_WST_QKV") == nullptr;
-    const bool xst = bst && e->xstore_on && wst_env && !e->fp8_fwd && E == 256 && F == 2 * E;
+    const bool xst = bst && e->xstore_on && wst_env && E == 256 && F == 2 * E;
     a.xst = xst;
     // ... and so are the pre-LayerNorm sums the backward pass re-reads (xhat = (r - mean) * rstd with the fp32 statistics of the
     // unrounded sum: a 2^-9 perturbation of xhat, the same order as the bf16 operands of every product around it)

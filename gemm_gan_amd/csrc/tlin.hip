@@ -1004,7 +1004,8 @@ bool tlin_supported(const TlinP& p) {
     if (p.res && (!al16(p.res) || p.ldres % 4)) return false;
     if (p.ln_g && (!al16(p.ln_g) || !al16(p.ln_b) || !al16(p.ln_y))) return false;
     if (p.y_bf16 && p.accumulate) return false;
-    if (p.ln_g && (p.res_bf16 || p.ln_y_bf16 || p.y_bf16)) return wst_routed(p) && wst_ln_supported(p);      // bf16 residual / LN output / pre-LN sum: wst.hip only
+    if (p.ln_g && (p.res_bf16 || p.ln_y_bf16 || p.y_bf16))       // bf16 residual / LN output / pre-LN sum: wst.hip only
+        return p.fp8 ? wst_fp8_kind(p) != 0 : (wst_routed(p) && wst_ln_supported(p));
     if (p.drop.p > 0.f && p.drop_ld % 2) return false;      // the epilogues hash element PAIRS (drop_rng.h)
     if (!needs_resident(p)) return (size_t)p.N * 4 <= 64 * 1024;     // bias vector in LDS
     if (p.mask_ref || p.act_relu || p.y_bf16) return false;   // not implemented in the resident epilogue
@@ -1030,7 +1031,7 @@ int tlin_kernel_class(const TlinP& p) {
     if (wst_routed(p)) return wst_ln_supported(p) ? (p.K == 256 ? 32 : 33) : (wst_kind(p) >= 6 ? 40 + wst_kind(p) : 33 + wst_kind(p));      // 32 .. 38, 46
     if (p.fp8) {
         static const bool no_wst8 = getenv("GG_NO_WST") != nullptr || getenv("GG_NO_WST8") != nullptr;
-        if (!no_wst8 && wst_fp8_kind(p)) return 41 + wst_fp8_kind(p);        // 42 .. 45
+        if (!no_wst8 && wst_fp8_kind(p)) return (wst_fp8_kind(p) >= 5 ? 46 : 41) + wst_fp8_kind(p);        // 42 .. 45, 51, 52
         return p.ln_g ? 39 : (p.drop.p > 0.f ? 41 : 40);
     }
     if (!needs_resident(p)) {
@@ -1057,8 +1058,8 @@ bool wst_routed(const TlinP& p);
 bool tlin_fp8_supported(const TlinP& p) {
     if (!p.fp8 || !p.w_exp || !tlin_supported(p)) return false;
     if (p.film_g || p.mask_ref || p.accumulate || p.y_row_group) return false;
-    if (p.ln_g) return p.N == 256 && p.K % 256 == 0 && p.x_bf16 && p.res && !p.act_relu && !p.y_bf16;
-    return p.K == 256 && !p.x_bf16 && p.y_bf16 && !p.res;
+    if (p.ln_g) return p.N == 256 && p.K % 256 == 0 && p.x_bf16 && p.res && !p.act_relu && (!p.y_bf16 || wst_fp8_kind(p) != 0);
+    return p.K == 256 && (!p.x_bf16 || wst_fp8_kind(p) != 0) && p.y_bf16 && !p.res;
 }
 
 int tlin(const TlinP& p_in, hipStream_t st) {

@@ -591,11 +591,13 @@ int wst_fp8_kind(const TlinP& p) {
     if (!al16(p.X) || !al16(p.W) || !al16(p.Y) || p.ldw % 16 || p.ldx % (p.x_bf16 ? 8 : 4)) return 0;
     if (p.drop.p > 0.f && p.drop_ld % 2) return 0;
     if (p.ln_g) {
-        if (!(p.ln_b && p.ln_y && p.ln_stats && p.res && p.x_bf16 && !p.act_relu && !p.y_bf16 && p.N == 256)) return 0;
+        if (!(p.ln_b && p.ln_y && p.ln_stats && p.res && p.x_bf16 && !p.act_relu && p.N == 256)) return 0;
         if (!al16(p.res) || !al16(p.ln_y) || p.ldy % 4 || p.ldres % 4) return 0;
+        if ((p.res_bf16 && p.ldres % 8) || ((p.ln_y_bf16 || p.y_bf16) && p.ldy % 8)) return 0;
         return p.K == 256 ? 1 : (p.K == 512 ? 2 : 0);
     }
-    if (p.res || !p.y_bf16 || p.x_bf16 || p.K != 256 || p.ldy % 8) return 0;
+    if (p.res || !p.y_bf16 || p.K != 256 || p.ldy % 8) return 0;
+    if (p.x_bf16) return p.N == 512 ? 5 : (p.N == 768 ? 6 : 0);           // bf16-stored LayerNorm outputs as X
     return p.N == 512 ? 3 : (p.N == 768 ? 4 : 0);
 }
 int wst_fp8(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -604,6 +606,8 @@ int wst_fp8(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         case 2: return launch<8, 1, 32, true, EPI_LN, true>(p, st, ev0, ev1);
         case 3: return launch<8, 2, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
         case 4: return launch<8, 3, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
+        case 5: return launch<8, 2, 16, true, EPI_ACT, true>(p, st, ev0, ev1);
+        case 6: return launch<8, 3, 16, true, EPI_ACT, true>(p, st, ev0, ev1);
     }
     set_error("wst_fp8: no instantiation for this call");
     return -2;

@@ -76,8 +76,10 @@ def test_fp8_linears_equal_the_product_of_the_quantised_operands(case):
             err = float((got - want[name]).abs().max() / want[name].abs().max())
             worst = max(worst, err)
             diag(f"   layer {l} {name:4s} max-norm error vs emulation {err:.3e}")
-            # bf16-stored outputs carry one bf16 rounding (2^-9 relative per element); fp32 ones only accumulation order
-            assert err <= (6e-3 if name in ("qkv", "h") else 2e-4), (l, name, err)
+            # bf16-stored outputs carry one bf16 rounding (2^-9 relative per element); fp32 ones only accumulation order.  At the
+            # production width x1 and the first layer's x2 are bf16-stored too (engine.hip "xst"), and the bf16 x1 is the residual of x2
+            stored_bf16 = name in ("qkv", "h") or (E == 256 and (name == "x1" or (name == "x2" and l == 0)))
+            assert err <= (6e-3 if stored_bf16 else 2e-4), (l, name, err)
         x_in = x2
     diag(f"   worst {worst:.3e}")
 
