@@ -81,11 +81,21 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+PMC_SUMMARIES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+def pmc_source():
+    for f in PMC_SUMMARIES:
+        if os.path.exists(os.path.join(ROOT, "profiles", f)):
+            return f
+    return None
+
+
 def pmc_traffic(cls):
     """Launch-weighted mean HBM bytes per launch of the kernels in class `cls`, from the committed PMC summary
     (measured offline with rocprofv3 on this same command; bench.py cannot host the profiler itself)."""
     data = None
-    for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):        # newest committed summary first
+    for f in PMC_SUMMARIES:                                            # newest committed summary first
         try:
             data = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"]
             break
@@ -131,7 +141,7 @@ def algorithmic_step(variant, B, G, P, T, Dt, Dp=1024, E=256, H=256, Lz=256, F=5
 def pmc_step_bytes(args):
     """HBM bytes of one step through the PMC counters, from the committed summary of this round (tools/pmc_traffic.sh on this
     same command); None when the summary is of another workload."""
-    for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for f in PMC_SUMMARIES[:2]:
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
         except Exception:
@@ -400,7 +410,7 @@ def main():
                                "frac": round(frac_m if bound == "mfma" else frac_h, 4), "traffic": traffic,
                                "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                                "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes, "
-                                               "profiles/r02_pmc_traffic.json; algorithmic bytes per launch = "
+                                               f"profiles/{pmc_source()}; algorithmic bytes per launch = "
                                                + str(round(dom["bytes"] / dom["launches"] / 1e6, 1)) + " MB",
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
                                "share_of_step": round(dom["ms"] / (dt * 1e3 * prof_steps / args.steps), 3),
@@ -410,18 +420,19 @@ def main():
                                        "small GEMMs per instantiation (classes carry the kernels' own names, as rocprofv3 prints "
                                        "them); `bound` is the side of the ridge its algorithmic FLOP/byte falls on - the attention "
                                        "kernels are in fact VALU-bound (exp2, dropout hash, conversions: ~25 ops per score), see "
-                                       "profiles/r02_pmc_mfma.json; achieved / frac are "
+                                       "profiles/r03_pmc_mfma.json; achieved / frac are "
                                        "live over the timed region, where it shares the chip with the parameter-gradient / prefetch "
                                        "kernels of the side streams; `isolated` is the same kernel in the serialised warm-up step. "
-                                       "In a rocprofv3 trace of the concurrent run the side-stream wgrad_kernel<true,false,false,false> "
-                                       "shows a larger total: its durations include waiting for compute units the main chain holds",
+                                       "The weight-gradient kernels run on the engine's side stream beside the main chain: their live "
+                                       "durations include waiting for compute units and HBM bandwidth the main chain holds",
                                "isolated": iso,
                                "gp_chain": gp_rows,
                                "gp_chain_note": "gradient-penalty kernels (R:351-374 closed form + double backward, 6 launches per critic "
                                                 "iteration incl. the dW1x weight-gradient and the split-K grad*W1x^T GEMM, which appear "
                                                 "under their own classes below); every tensor of the chain is <= B*G*4 = "
-                                                f"{B * G * 4 / 1e6:.1f} MB, i.e. <= {B * G * 4 / 8e6:.2f} us at the HBM peak: launch-latency-"
-                                                "bound by construction at this minibatch",
+                                                f"{B * G * 4 / 1e6:.1f} MB ({B * G * 4 / 8e6:.2f} us at the HBM peak); gp_grad_k = g1 W1x with the "
+                                                "row norms in its epilogue (split-operand strip kernel, fp32-grade products; 41 us in "
+                                                "round 2, 12 us now)",
                                "time_weighted": (lambda rs: {
                                    "note": "all classes of the table, each priced against the roof its algorithmic intensity falls under "
                                            "(HBM below the ridge, MFMA above), weighted by their time in the serialised step",
