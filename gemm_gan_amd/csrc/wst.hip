@@ -79,7 +79,11 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // GROUPS > 1: the output has GROUPS * N columns (the packed QKV projection: 3 x 256) and the grid holds GROUPS workgroups per
 // token-tile owner, each stationary on its own N rows of W and streaming the SAME tiles; the block index is decoded so that
 // the groups of one owner sit on one XCD (ids that differ by multiples of 8) and re-read the tile from that XCD's L2.
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
+// PF: the epilogue's per-token operands (EPI_LN: the bf16 residual rows; EPI_MASK: the gate reference rows) are requested ONE TILE
+// AHEAD into a second register set.  Requested at the start of their own tile they have only the MFMA phase (~0.5 - 0.9 us) to
+// arrive, and the waves then sit out the rest of an HBM round trip in the epilogue: 43 - 57 % of the wave time of these kernels
+// was s_waitcnt (profiles/r03_pmc_mfma.json).  bf16 operands only (8 registers per row tile and set).
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1, bool PF = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
     const int grp = GROUPS > 1 ? (int)(blockIdx.x >> 3) % GROUPS : 0;
@@ -177,13 +181,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
 
     long tile = owner;
     if (tile >= ntiles) return;
+    // Every load of the tile pipeline is UNCONDITIONAL (tile indices clamped to the last tile; rows are clamped inside load_x):
+    // with `if (next tile exists) load` the compiler's wait-count pass sees paths with and without loads in flight and falls back
+    // to s_waitcnt vmcnt(0) before the epilogue - which waits for the rows of the tile AFTER next that were requested a moment
+    // before, i.e. the register prefetch collapses to nothing (found in the ISA; 43 - 57 % of these kernels' wave time was waits).
     load_x(tile);
     store_x(0);
-    if (tile + nown < ntiles) load_x(tile + nown);
+    load_x(min(tile + nown, ntiles - 1));
     const float ksd = p.drop.p > 0.f ? 1.f / (1.f - p.drop.p) : 1.f;
     const bool drop_on = p.drop.p > 0.f;
 
     float col_g = 0.f, col_b = 0.f, col_c = 0.f;        // EPI_LNB: this lane's column sums (feature f0 + 16 h + colsum16's index)
+    static_assert(!PF || EPI == EPI_LN || EPI == EPI_MASK, "one-tile-ahead epilogue operands: LayerNorm residual / gate reference");
+    u32x4 ecur[PF ? RT : 1][2], enxt[PF ? RT : 1][2];
+    auto request_epi = [&](long tl, u32x4 (&dst)[PF ? RT : 1][2]) {
+        const int tk = min((int)(tl * TT) + c, last_tok);
+        const __bf16* src = EPI == EPI_LN ? reinterpret_cast<const __bf16*>(p.res) + (long)(tk % (int)p.res_rows) * p.ldres + f0 + 16 * h
+                                          : reinterpret_cast<const __bf16*>(p.mask_ref) + (long)tk * p.ldref + f0 + 16 * h;
+#pragma unroll
+        for (int rt = 0; rt < (PF ? RT : 1); ++rt) {
+            dst[rt][0] = *reinterpret_cast<const u32x4*>(src + 32 * rt);
+            dst[rt][1] = *reinterpret_cast<const u32x4*>(src + 32 * rt + 8);
+        }
+    };
+    if constexpr (PF) request_epi(tile, ecur);
     int buf = 0;
     for (; tile < ntiles; tile += nown, buf ^= 1) {
         const int tok = (int)(tile * TT) + c;
@@ -193,10 +214,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
         __syncthreads();                                // X(tile) is in Xs[buf]; Red[buf] of two tiles ago has been consumed
         // epilogue operands of this tile (residual rows / previous output / gate reference): requested before the products
         f32x4 res[EPI == EPI_LN || EPI == EPI_ACC || EPI == EPI_LNB ? RT : 1][4];
-        f32x4 rpre[EPI == EPI_LNB ? RT : 1][4];          // EPI_LNB: the pre-LayerNorm sums of the token
+        f32x4 rpre[EPI == EPI_LNB ? RT : 1][4];          // EPI_LNB: the pre-LayerNorm sums of the token (bf16 form: raw words in [0], [1],
+                                                         // expanded only in the epilogue - a conversion here would wait for the load at once)
         float2 lstat = float2{0.f, 1.f};
         u32x4 mref[EPI == EPI_MASK ? RT : 1][2];
-        if constexpr (EPI == EPI_LN) {
+        if constexpr (PF) {
+            request_epi(min(tile + nown, ntiles - 1), enxt);      // the NEXT tile's rows (the last tile re-requests its own)
+        } else if constexpr (EPI == EPI_LN) {
             if (p.res_bf16) {
                 const __bf16* resp = reinterpret_cast<const __bf16*>(p.res) + (long)(tokc % (int)p.res_rows) * p.ldres + f0 + 16 * h;
 #pragma unroll
@@ -216,13 +240,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
             static_assert(EPI != EPI_LNB || (RT == 1 && GROUPS == 1 && !F8), "LayerNorm-backward epilogue: 8 waves x 32 features");
             if (p.res_bf16) {
                 const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + (long)tokc * p.ldres + f0 + 16 * h;
-                const u32x4 w0 = *reinterpret_cast<const u32x4*>(rp), w1 = *reinterpret_cast<const u32x4*>(rp + 8);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned a = g < 2 ? w0[2 * (g & 1)] : w1[2 * (g & 1)], b = g < 2 ? w0[2 * (g & 1) + 1] : w1[2 * (g & 1) + 1];
-                    rpre[0][g] = f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u),
-                                       __builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
-                }
+                rpre[0][0] = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(rp));
+                rpre[0][1] = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(rp + 8));
             } else {
                 const float* rp = p.res + (long)tokc * p.ldres + f0 + 16 * h;
 #pragma unroll
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
 #pragma unroll
                 for (int g = 0; g < 4; ++g) res[rt][g] = *reinterpret_cast<const f32x4*>(yo + 32 * rt + 4 * g);
         }
-        if constexpr (EPI == EPI_MASK) {
+        if constexpr (EPI == EPI_MASK && !PF) {
             const __bf16* mr = reinterpret_cast<const __bf16*>(p.mask_ref) + (long)tokc * p.ldref + f0 + 16 * h;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -245,6 +264,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
                 mref[rt][1] = *reinterpret_cast<const u32x4*>(mr + 32 * rt + 8);
             }
         }
+        // keep the epilogue-operand requests above the MFMA block: left to itself the scheduler sinks them below it (register
+        // pressure), where they sit behind the NEXT tile's row requests and the epilogue waits for everything (vmcnt(0))
+        if constexpr (EPI == EPI_ACC || PF) __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -269,14 +291,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
             }
         }
         // the next tile's rows (already in registers) go to the other buffer, the tile after that is requested
-        if (tile + nown < ntiles) {
-            store_x(buf ^ 1);
-            if (tile + 2L * nown < ntiles) load_x(tile + 2L * nown);
-        }
+        store_x(buf ^ 1);          // (after the last tile: rows nobody reads)
+        load_x(min(tile + 2L * nown, ntiles - 1));
         if constexpr (EPI == EPI_LNB) {
             // ---- += then LayerNorm backward: dy = Y + acc; dr = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) -------------------
             const float mean = lstat.x, rstd = lstat.y;
             const float nmr = -mean * rstd;              // xhat = r * rstd + nmr, recomputed where it is needed (no second 16-register copy)
+            if (p.res_bf16) {                            // expand the raw bf16 words (high groups first: [0], [1] are overwritten last)
+                const u32x4 w0 = __builtin_bit_cast(u32x4, rpre[0][0]), w1 = __builtin_bit_cast(u32x4, rpre[0][1]);
+#pragma unroll
+                for (int g = 3; g >= 0; --g) {
+                    const unsigned a = g < 2 ? w0[2 * (g & 1)] : w1[2 * (g & 1)], b = g < 2 ? w0[2 * (g & 1) + 1] : w1[2 * (g & 1) + 1];
+                    rpre[0][g] = f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u),
+                                       __builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
+                }
+            }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -369,7 +398,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
                         }
                     }
                     if constexpr (EPI == EPI_MASK) {
-                        const unsigned w0 = mref[rt][g >> 1][2 * (g & 1)], w1 = mref[rt][g >> 1][2 * (g & 1) + 1];
+                        const u32x4 mw = PF ? ecur[PF ? rt : 0][g >> 1] : mref[rt][g >> 1];
+                        const unsigned w0 = mw[2 * (g & 1)], w1 = mw[2 * (g & 1) + 1];
                         const float m[4] = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
                                             __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
 #pragma unroll
@@ -406,8 +436,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
-                if (p.res_bf16) {
-                    const u32x4 rw = __builtin_bit_cast(u32x4, res[rt][g >> 1]);
+                if (PF || p.res_bf16) {
+                    const u32x4 rw = PF ? ecur[PF ? rt : 0][g >> 1] : __builtin_bit_cast(u32x4, res[rt][g >> 1]);
                     const unsigned w0 = rw[2 * (g & 1)], w1 = rw[2 * (g & 1) + 1];
                     v += f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
                                __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
@@ -472,6 +502,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
             p.ln_stats[2 * (long)tok + 1] = rstd;
         }
         }       // EPI_LN
+        if constexpr (PF) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { ecur[rt][0] = enxt[rt][0]; ecur[rt][1] = enxt[rt][1]; }
+        }
     }
     if constexpr (EPI == EPI_LNB) {
         if (!(c & 1)) {         // odd lanes hold the same totals
@@ -483,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KS >= 48) ? 1 : 2) void wst_ln
     }
 }
 
-template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1>
+template <int NW, int RT, int KS, bool XB = true, int EPI = EPI_LN, bool F8 = false, int GROUPS = 1, bool PF = false>
 int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     static_assert(GROUPS == 1 || ((EPI == EPI_ACT || EPI == EPI_ACC) && !F8), "column groups: the plain epilogues only");
     constexpr int K = 16 * KS, N = 32 * NW * RT;
@@ -491,7 +525,7 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int dev = 0;
         GG_CHECK_HIP(hipGetDevice(&dev));
         GG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -510,8 +544,8 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
         const long owners = std::max<long>(8, std::min<long>((ntiles + 7) / 8 * 8, slots / GROUPS / 8 * 8));
         grid = (unsigned)(owners * GROUPS);
     }
-    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
-    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS>), dim3(grid), dim3(64 * NW), smem, st, p);
+    if (ev0) hipExtLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS, PF>), dim3(grid), dim3(64 * NW), (unsigned)smem, st, ev0, ev1, 0, p);
+    else hipLaunchKernelGGL((wst_ln_kernel<NW, RT, KS, XB, EPI, F8, GROUPS, PF>), dim3(grid), dim3(64 * NW), smem, st, p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -531,6 +565,11 @@ bool wst_ln_supported(const TlinP& p) {
 
 int wst_ln(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     GG_REQUIRE(wst_ln_supported(p), "wst_ln: unsupported shape / alignment");
+    static const bool no_pf = getenv("GG_NO_WST_PF") != nullptr;
+    if (p.res_bf16 && !no_pf) {       // bf16 residual rows: requested one tile ahead
+        if (p.K == 256) return launch<4, 2, 16, true, EPI_LN, false, 1, true>(p, st, ev0, ev1);
+        return launch<8, 1, 32, true, EPI_LN, false, 1, true>(p, st, ev0, ev1);
+    }
     if (p.K == 256) return launch<4, 2, 16>(p, st, ev0, ev1);
     return launch<8, 1, 32>(p, st, ev0, ev1);
 }
@@ -616,7 +655,10 @@ int wst_other(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     switch (wst_kind(p)) {
         case 1: return launch<8, 1, 32, true, EPI_ACC>(p, st, ev0, ev1);
         case 2: return launch<8, 2, 16, false, EPI_ACT>(p, st, ev0, ev1);
-        case 3: return launch<8, 2, 16, true, EPI_MASK>(p, st, ev0, ev1);
+        case 3: {
+            static const bool no_pf = getenv("GG_NO_WST_PF") != nullptr;
+            return no_pf ? launch<8, 2, 16, true, EPI_MASK>(p, st, ev0, ev1) : launch<8, 2, 16, true, EPI_MASK, false, 1, true>(p, st, ev0, ev1);
+        }
         case 4: return launch<4, 2, 16, true, EPI_ACT>(p, st, ev0, ev1);
         case 5: return launch<8, 1, 48, true, EPI_ACC>(p, st, ev0, ev1);
         case 6: return launch<4, 2, 16, false, EPI_ACT, false, 3>(p, st, ev0, ev1);
