@@ -28,6 +28,7 @@
 
 namespace gg {
 namespace {
+enum { EM_NONE = 0, EM_RES = 1, EM_ACC = 2, EM_MREF = 3, EM_ANY = 4 };      // epilogue operand modes of tlin3_kernel
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -177,24 +178,40 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     bf16x8 xf[NS][KSL / 16];
     // epilogue operands (residual rows / previous output, gate reference) travel one feature tile ahead of their use: tile 0 is
     // requested before the last MFMA pass, tile nt + 1 while tile nt is finished (all of them up front cost 128 registers: spills)
+    // The requests carry NO run-time condition: which operands exist is a compile-time mode of the epilogue (EM_*; the kernel
+    // branches once, wave-uniformly, into the matching copy).  With `if (resp) load` inside the loop the wait-count pass waited
+    // for every request where it was issued (vmcnt(0)): the one-tile-ahead prefetch did not exist.
     f32x4 pre[2][4], mrf[2][4];
-    auto load_pre = [&](int nt) {
+    auto load_pre = [&](int nt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nt * 32 + 8 * g + 4 * h;
-            if (has_pre) {
-                pre[nt & 1][g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.accumulate) pre[nt & 1][g] += *reinterpret_cast<const f32x4*>(yb + n);
+            if constexpr (MODE == EM_RES) pre[nt & 1][g] = *reinterpret_cast<const f32x4*>(resp + n);
+            if constexpr (MODE == EM_ACC) pre[nt & 1][g] = *reinterpret_cast<const f32x4*>(yb + n);
+            if constexpr (MODE == EM_MREF) mrf[nt & 1][g] = *reinterpret_cast<const f32x4*>(mref + n);
+            if constexpr (MODE == EM_ANY) {
+                if (has_pre) {
+                    pre[nt & 1][g] = resp ? *reinterpret_cast<const f32x4*>(resp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.accumulate) pre[nt & 1][g] += *reinterpret_cast<const f32x4*>(yb + n);
+                }
+                if (mref) mrf[nt & 1][g] = *reinterpret_cast<const f32x4*>(mref + n);
             }
-            if (mref) mrf[nt & 1][g] = *reinterpret_cast<const f32x4*>(mref + n);
         }
     };
+    const int emode = (!has_pre && !mref) ? EM_NONE : (resp && !p.accumulate && !mref) ? EM_RES : (!resp && p.accumulate && !mref) ? EM_ACC
+                      : (!has_pre && mref) ? EM_MREF : EM_ANY;
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
         xst.commit(p, xs, tok0, last_tok, lane);
         if (ks + 1 < nks) xst.request(p, tok0, last_tok, (ks + 1) * KSL, lane);
-        if (ks == nks - 1) load_pre(0);
+        if (ks == nks - 1) {      // (outside the steady state: the branch costs one conservative wait in the last slice)
+            if (emode == EM_RES) load_pre(0, std::integral_constant<int, EM_RES>());
+            else if (emode == EM_ACC) load_pre(0, std::integral_constant<int, EM_ACC>());
+            else if (emode == EM_MREF) load_pre(0, std::integral_constant<int, EM_MREF>());
+            else if (emode == EM_ANY) load_pre(0, std::integral_constant<int, EM_ANY>());
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -208,7 +225,9 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 #pragma unroll
         for (int nt = 0; nt < NT_RES; ++nt) {
             const int buf = nt & 1;      // compile-time after unrolling (NT_RES is even): chunk & 1 == nt & 1
-            if (chunk + 2 < nchunks) load_chunk(buf, nt + 2 >= NT_RES ? ks + 1 : ks, (nt + 2) % NT_RES);
+            // unconditional (the k-slice index clamped; the last two requests fetch chunks nobody uses): a run-time condition around
+            // these loads makes the wait-count pass drain them at the end of the SAME chunk (vmcnt(0)) instead of one chunk later
+            load_chunk(buf, min(nt + 2 >= NT_RES ? ks + 1 : ks, nks - 1), (nt + 2) % NT_RES);
             if (ks == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[1][s], acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[0][s], acc[nt], 0, 0, 0);
             }
-            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+            store_chunk(buf ^ 1);          // (after the last chunk: a buffer nobody reads)
             __syncthreads();
             ++chunk;
         }
@@ -246,9 +265,11 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
     const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
     const uint64_t dbase = (uint64_t)tokc * p.drop_ld + gcol;
     float sum = 0.f;
+    auto epilogue = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
     for (int nt = 0; nt < NT_RES; ++nt) {
-        if (nt + 1 < NT_RES) load_pre(nt + 1);
+        if (nt + 1 < NT_RES) load_pre(nt + 1, mode_tag);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nt * 32 + 8 * g + 4 * h;
@@ -265,12 +286,12 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= f[j];
             }
-            if (mref) {
+            if (MODE == EM_MREF || (MODE == EM_ANY && mref)) {
                 const f32x4 m = mrf[nt & 1][g];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] * p.mask_scale : 0.f;
             }
-            if (has_pre) v += pre[nt & 1][g];
+            if (MODE == EM_RES || MODE == EM_ACC || (MODE == EM_ANY && has_pre)) v += pre[nt & 1][g];
             if (valid && keep_y) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -280,6 +301,12 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    };
+    if (emode == EM_NONE) epilogue(std::integral_constant<int, EM_NONE>());
+    else if (emode == EM_RES) epilogue(std::integral_constant<int, EM_RES>());
+    else if (emode == EM_ACC) epilogue(std::integral_constant<int, EM_ACC>());
+    else if (emode == EM_MREF) epilogue(std::integral_constant<int, EM_MREF>());
+    else epilogue(std::integral_constant<int, EM_ANY>());
     if (p.ln_g) {
         const float invn = 1.f / (float)N;
         sum += __shfl_xor(sum, 32, 64);
