@@ -24,6 +24,15 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
+// Ablation switches of tools/tlin_probe (GG_TLIN_DBG bits: 1 no stores, 2 no MFMA, 4 no weight loads, 8 no X loads, 16 no epilogue
+// operands, 32 no dropout) exist only in a probe build (-DGG_TLIN_DBG_RT): as run-time tests they put a condition around every
+// load of the production kernels, and the compiler's wait-count pass then waits for a load where it is issued (vmcnt(0)).
+#ifdef GG_TLIN_DBG_RT
+#define TLIN_DBG(bit) (p.dbg & (bit))
+#else
+#define TLIN_DBG(bit) false
+#endif
+
 namespace gg {
 
 namespace {
@@ -281,9 +290,9 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 
     int chunk = 0;
     for (int ks = 0; ks < nks; ++ks) {
-        if (!(p.dbg & 8)) stage_x<KSL, WLD, XB>(p, xs, tok0, last_tok, ks * KSL, lane);
+        if (!TLIN_DBG(8)) stage_x<KSL, WLD, XB>(p, xs, tok0, last_tok, ks * KSL, lane);
         if constexpr (PRE != PRE_NONE) {
-            if (ks == nks - 1 && !(p.dbg & 16)) load_pre(0, NT_RES / 2);
+            if (ks == nks - 1 && !TLIN_DBG(16)) load_pre(0, NT_RES / 2);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -296,13 +305,13 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
 #pragma unroll
         for (int nt = 0; nt < NT_RES; ++nt) {
             const int buf = nt & 1;      // compile-time after unrolling
-            if (chunk + 2 < nchunks && !(p.dbg & 4)) load_chunk(buf, nt + 2 >= NT_RES ? ks + 1 : ks, (nt + 2) % NT_RES);
+            if (!TLIN_DBG(4)) load_chunk(buf, min(nt + 2 >= NT_RES ? ks + 1 : ks, nks - 1), (nt + 2) % NT_RES);      // unconditional: the last two fetch chunks nobody uses
             if (ks == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             }
             if constexpr (PRE != PRE_NONE) {
-                if (nt == NT_RES / 2 && ks == nks - 1 && !(p.dbg & 16)) load_pre(NT_RES / 2, NT_RES);
+                if (nt == NT_RES / 2 && ks == nks - 1 && !TLIN_DBG(16)) load_pre(NT_RES / 2, NT_RES);
             }
             const __bf16* wsb = Ws + buf * 32 * WLD + c * WLD + 8 * h;
 #pragma unroll
@@ -310,12 +319,12 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 bf16x8 wf[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
-                if (!(p.dbg & 2)) {
+                if (!TLIN_DBG(2)) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc[nt], 0, 0, 0);
                 }
             }
-            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+            store_chunk(buf ^ 1);          // (after the last chunk: a buffer nobody reads)
             __syncthreads();
             ++chunk;
         }
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                     for (int j = 0; j < 4; ++j) v[j] *= f[j];
                 }
                 if constexpr (PRE != PRE_NONE) v += pre[nt][g];
-                if ((!PRED || valid) && keep_y && !((p.dbg & 1) && v[0] != 1234.5f)) *reinterpret_cast<f32x4*>(yb + n) = v;
+                if ((!PRED || valid) && keep_y && !(TLIN_DBG(1) && v[0] != 1234.5f)) *reinterpret_cast<f32x4*>(yb + n) = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[nt][4 * g + j] = v[j];
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
             __builtin_amdgcn_sched_barrier(0);     // one feature tile at a time: LDS reads are not hoisted across tiles
         }
     };
-    if (p.drop.p > 0.f && !(p.dbg & 32)) epilogue(std::true_type{});
+    if (p.drop.p > 0.f && !TLIN_DBG(32)) epilogue(std::true_type{});
     else epilogue(std::false_type{});
 
     if (p.ln_g) {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void tlin_res_kernel(const TlinP p) {
                 f32x4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = (acc[nt][4 * g + j] - mean) * rstd * gg_[j] + bb[j];
-                if ((!PRED || valid) && !((p.dbg & 1) && y[0] != 1234.5f)) *reinterpret_cast<f32x4*>(lb + n) = y;
+                if ((!PRED || valid) && !(TLIN_DBG(1) && y[0] != 1234.5f)) *reinterpret_cast<f32x4*>(lb + n) = y;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
 #pragma unroll
     for (int q = 0; q < KSL / XW; ++q) {
         if constexpr (F8) stage_x8<XW, XLDW, XB, 32>(p, xs8, tok0, last_tok, q * XW, lane, xscale);
-        else if (!(p.dbg & 8)) stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
+        else if (!TLIN_DBG(8)) stage_x<XW, XLDW, XB>(p, xs, tok0, last_tok, q * XW, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if constexpr (F8) {
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
     const long mbase = (long)tokc * p.ldref + hoff;
     const uint64_t dbase = (uint64_t)tokc * p.drop_ld;
     const float floor_ = p.act_relu ? 0.f : -__builtin_inff();
-    const bool drop_on = (EPI == EPI_DROP || (EPI == EPI_ANY && p.drop.p > 0.f)) && !(p.dbg & 32);
+    const bool drop_on = (EPI == EPI_DROP || (EPI == EPI_ANY && p.drop.p > 0.f)) && !TLIN_DBG(32);
     const bool mask_on = EPI == EPI_MASK || (EPI == EPI_ANY && p.mask_ref != nullptr);
     const bool acc_on = EPI == EPI_ANY && !YB && p.accumulate;
     const float ksd = drop_on ? 1.f / (1.f - p.drop.p) : 1.f;
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
     auto tile = [&](auto slot_tag, int nt) {
         constexpr int slot = decltype(slot_tag)::value;
         constexpr int buf = slot & 1;
-        if (nt + 2 < ntiles && !(p.dbg & 4)) load_chunk(buf, nt + 2);
+        if (nt + 2 < ntiles && !TLIN_DBG(4)) load_chunk(buf, nt + 2);
         // operands of this tile's epilogue are requested before the MFMA chain
         f32x4 mm[4], yy[4];
         if (mask_on) {
@@ -759,7 +768,7 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
             bf16x8 wf[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wsb + 16 * (4 * s4 + u));
-            if (!(p.dbg & 2)) {
+            if (!TLIN_DBG(2)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], xf[4 * s4 + u], acc, 0, 0, 0);
             }
@@ -788,13 +797,13 @@ __global__ __launch_bounds__(256, GG_STR_OCC) void tlin_str_kernel(const TlinP p
                 held[slot][2 * g] = pack2(v[0], v[1]);
                 held[slot][2 * g + 1] = pack2(v[2], v[3]);
             } else {
-                if ((!PRED || valid) && !((p.dbg & 1) && v[0] != 1234.5f))
+                if ((!PRED || valid) && !(TLIN_DBG(1) && v[0] != 1234.5f))
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + ybase + nt * 32 + GS * g) = v;
             }
         }
         if constexpr (YB) {     // 16 consecutive features of this lane's row per chunk: two 16-byte stores each
             if (slot == CB - 1 || nt + 1 == ntiles) {
-                if ((!PRED || valid) && !((p.dbg & 1) && held[0][0] != 0x12345u)) {
+                if ((!PRED || valid) && !(TLIN_DBG(1) && held[0][0] != 0x12345u)) {
                     __bf16* yp = reinterpret_cast<__bf16*>(p.Y) + ybase + (nt - slot) * 32;
 #pragma unroll
                     for (int q = 0; q <= slot; ++q) {

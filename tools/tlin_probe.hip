@@ -1,5 +1,5 @@
 // Standalone timing harness for the token-on-lane Linear kernels (tools only; includes the kernel source directly).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gemm_gan_amd/csrc tools/tlin_probe.hip -o tools/tlin_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGG_TLIN_DBG_RT -I gemm_gan_amd/csrc tools/tlin_probe.hip -o tools/tlin_probe
 //   ./tools/tlin_probe <case> [M]     cases: qkv ffn1 outproj ffn2 dmask
 #include "../gemm_gan_amd/csrc/tlin.hip"
 #include <stdio.h>
