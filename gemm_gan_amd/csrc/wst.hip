@@ -641,8 +641,8 @@ int wst_fp8_kind(const TlinP& p) {
 }
 int wst_fp8(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     switch (wst_fp8_kind(p)) {
-        case 1: return launch<4, 2, 16, true, EPI_LN, true>(p, st, ev0, ev1);
-        case 2: return launch<8, 1, 32, true, EPI_LN, true>(p, st, ev0, ev1);
+        case 1: return p.res_bf16 ? launch<4, 2, 16, true, EPI_LN, true, 1, true>(p, st, ev0, ev1) : launch<4, 2, 16, true, EPI_LN, true>(p, st, ev0, ev1);
+        case 2: return p.res_bf16 ? launch<8, 1, 32, true, EPI_LN, true, 1, true>(p, st, ev0, ev1) : launch<8, 1, 32, true, EPI_LN, true>(p, st, ev0, ev1);
         case 3: return launch<8, 2, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
         case 4: return launch<8, 3, 16, false, EPI_ACT, true>(p, st, ev0, ev1);
         case 5: return launch<8, 2, 16, true, EPI_ACT, true>(p, st, ev0, ev1);
