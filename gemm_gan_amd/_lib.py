@@ -95,6 +95,7 @@ SYMBOLS = {
     "gg_set_ffn_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_xstore": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_lnb_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_head_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_test_ffn_fused": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p]),
@@ -137,6 +138,10 @@ SYMBOLS = {
                                   C.c_int, C.c_void_p]),
     "gg_test_sqx_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gg_test_head_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gg_test_head_bwd": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gg_test_ln_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "gg_launch_count": (C.c_int64, [C.c_void_p]),

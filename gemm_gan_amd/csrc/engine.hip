@@ -229,6 +229,8 @@ struct gg_engine {
     int str_cls[40] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
+    int head_on = getenv("GG_HEAD_FUSED") != nullptr;     // MLP heads as one forward and one backward launch (head.hip), bf16 mode: opt-in -
+                               // measured equal to the nine launches it replaces (configs[0] 1.44 vs 1.47 ms, cfg3 25.25 vs 25.17 ms)
     int lnb_on = getenv("GG_NO_WST_LNB") == nullptr;      // dx1 += and LN1 backward in one weight-stationary kernel (production width, bf16 mode)
     int rstore_on = getenv("GG_NO_RSTORE") == nullptr;    // ... and of the pre-LayerNorm sums kept for the backward pass
     int xstore_on = getenv("GG_NO_XSTORE") == nullptr;   // bf16 storage of the encoder's LayerNorm outputs (production width, bf16 mode)
@@ -1503,6 +1505,19 @@ int head_finish(Ctx& c, Net& n, const float* cvec, float* a1, float* a2, float* 
     const int E = e->E, H = e->H;
     const float* w = n.w;
     const float slope = e->cfg.negative_slope;
+    if (e->head_on && e->precision == GG_PREC_BF16 && !e->x3) {       // the chain in one launch (head.hip); the generator's wide output layer stays a GEMM
+        HeadP h;
+        h.rows = rows; h.H = H; h.E = E; h.slope = slope;
+        h.W1c = w + n.w1 + n.V; h.ldw1 = n.V + E; h.b1 = w + n.b1; h.W2 = w + n.w2; h.b2 = w + n.b2;
+        h.cvec = cvec; h.a1 = a1; h.a2 = a2;
+        const bool score = out && out_rows > 0 && n.OUT == 1;
+        if (score) { h.w3 = w + n.w3; h.b3 = w + n.b3; h.out = out; h.ldo = ldo; h.out_rows = out_rows; }
+        if (head_fused_supported(h)) {
+            KL(head_fwd(h, c.st));
+            if (out && out_rows > 0 && !score) GG_TRY(lin_fwd(c, a2, H, w + n.w3, H, w + n.b3, out, ldo, out_rows, n.OUT, H));
+            return 0;
+        }
+    }
     GG_TRY(lin_fwd(c, cvec, E, w + n.w1 + n.V, n.V + E, w + n.b1, a1, H, rows, H, E, ACT_LRELU, slope, 1));
     GG_TRY(lin_fwd(c, a1, H, w + n.w2, H, w + n.b2, a2, H, rows, H, H, ACT_LRELU, slope));
     if (out && out_rows > 0) GG_TRY(lin_fwd(c, a2, H, w + n.w3, H, w + n.b3, out, ldo, out_rows, n.OUT, H));
@@ -1530,8 +1545,23 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
         if (out_bias_grad) { GG_TRY(k_colsum(dout, rows, OUT, OUT, g + n.b3, cs.st)); e->launches++; }
         GG_TRY(side_end(c, fk, 3));
     }
-    GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));
-    KL(k_act_bwd(dh2, a2, (long)rows * H, slope, 1.f, c.st));
+    bool fused = false;
+    if (e->head_on && e->precision == GG_PREC_BF16 && !e->x3) {      // dh2, dh1 (and dcond) in one launch (head.hip)
+        HeadP h;
+        h.rows = rows; h.H = H; h.E = E; h.slope = slope;
+        h.W1c = w + n.w1 + V; h.ldw1 = V + E; h.W2 = w + n.w2; h.w3 = w + n.w3;
+        h.a1 = const_cast<float*>(a1); h.a2 = const_cast<float*>(a2); h.dh2 = dh2; h.dh1 = dh1; h.dcond = dcond;
+        if (head_fused_supported(h)) {
+            if (OUT == 1) h.dout = dout;
+            else GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));       // the generator's wide layer: dh2 <- dout W3
+            KL(head_bwd(h, c.st));
+            fused = true;
+        }
+    }
+    if (!fused) {
+        GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));
+        KL(k_act_bwd(dh2, a2, (long)rows * H, slope, 1.f, c.st));
+    }
     if (param_grads) {
         Ctx cs = c;
         const bool fk = side_begin(c, cs);
@@ -1539,8 +1569,10 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
         GG_TRY(k_colsum(dh2, rows, H, H, g + n.b2, cs.st)); e->launches++;
         GG_TRY(side_end(c, fk, 3));
     }
-    GG_TRY(lin_bwd_data(c, dh2, H, w + n.w2, H, dh1, H, rows, H, H));
-    KL(k_act_bwd(dh1, a1, (long)rows * H, slope, 1.f, c.st));
+    if (!fused) {
+        GG_TRY(lin_bwd_data(c, dh2, H, w + n.w2, H, dh1, H, rows, H, H));
+        KL(k_act_bwd(dh1, a1, (long)rows * H, slope, 1.f, c.st));
+    }
     if (param_grads) {
         Ctx cs = c;
         const bool fk = side_begin(c, cs);
@@ -1549,7 +1581,7 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
         GG_TRY(k_colsum(dh1, rows, H, H, g + n.b1, cs.st)); e->launches++;
         GG_TRY(side_end(c, fk, 3));
     }
-    if (dcond) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1 + V, V + E, dcond, E, rows, H, E));
+    if (dcond && !fused) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1 + V, V + E, dcond, E, rows, H, E));
     if (dv) GG_TRY(lin_bwd_data(c, dh1, H, w + n.w1, V + E, dv, V, rows, H, V));
     return 0;
 }
@@ -2153,7 +2185,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21 | (uint64_t)e->head_on << 22,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2312,6 +2344,11 @@ int gg_set_wgrad(gg_engine* e, int on) {
 int gg_set_bstore(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->bstore_on = on != 0;
+    return 0;
+}
+int gg_set_head_fused(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->head_on = on != 0;
     return 0;
 }
 int gg_set_lnb_fused(gg_engine* e, int on) {

@@ -242,6 +242,23 @@ int k_split_weights(const float* w, void* parts, long n, long part_stride, int n
 // e4m3 shadow: w8[2*off + i] = e4m3(w[off + i] * 2^w_exp[entry]), w_exp[entry] = floor(log2(448 / max|w|)); amax: scratch [n_entries]
 int k_shadow_weights_fp8(const float* w, void* w8, unsigned* amax, int* w_exp, const ShadowEntry* tab_dev, int n_entries, hipStream_t st);
 
+// fused MLP head (head.hip): forward  a1 = act(a1 + cvec W1c^T + b1), a2 = act(a1 W2^T + b2), out = a2 w3 + b3 (critic);
+// backward  dh2 = (dout w3^T | dh2) * act'(a2), dh1 = (dh2 W2) * act'(a1), dcond = dh1 W1c.  fp32 tensors, bf16 MFMA operands.
+struct HeadP {
+    long rows = 0; int H = 0, E = 0; float slope = 0.f;
+    const float* W1c = nullptr; long ldw1 = 0;          // [H][E] slice of the first layer's weight (row stride ldw1)
+    const float* b1 = nullptr; const float* W2 = nullptr; const float* b2 = nullptr;      // W2 [H][H] dense
+    const float* w3 = nullptr; const float* b3 = nullptr;                                 // [H], [1]: the critic's score column
+    const float* cvec = nullptr;                        // [rows][E]
+    float* a1 = nullptr; float* a2 = nullptr;           // [rows][H]; forward: a1 holds the gene / latent part on entry
+    float* out = nullptr; long ldo = 1; long out_rows = 0;                                // forward: scores of rows < out_rows (null: none)
+    const float* dout = nullptr;                        // backward, critic: d(score) [rows]; null: dh2 holds dout W3 on entry
+    float* dh2 = nullptr; float* dh1 = nullptr; float* dcond = nullptr;                   // [rows][H], [rows][H], [rows][E] (dcond may be null)
+};
+bool head_fused_supported(const HeadP& p);
+int head_fwd(const HeadP& p, hipStream_t st);
+int head_bwd(const HeadP& p, hipStream_t st);
+
 // single-query attention over un-projected keys/values (sqattn.hip) ------------------------------------------------
 bool sqx_supported(int S, int E, int nh);
 // q [N,E] projected query; x [N,S,E]; Win [3E,E], bin [3E] packed in-proj; probs [N,nh,S], xbar [N,nh,E], ctx [N,E]

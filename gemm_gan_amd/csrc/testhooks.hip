@@ -92,6 +92,24 @@ int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1
     return ffn_fused(f, (hipStream_t)stream);
 }
 
+int gg_test_head_fwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* b1, const float* W2,
+                     const float* b2, const float* w3, const float* b3, const float* cvec, float* a1, float* a2, float* out,
+                     int64_t out_rows, void* stream) {
+    HeadP h;
+    h.rows = rows; h.H = H; h.E = E; h.slope = slope; h.W1c = W1c; h.ldw1 = ldw1; h.b1 = b1; h.W2 = W2; h.b2 = b2; h.w3 = w3; h.b3 = b3;
+    h.cvec = cvec; h.a1 = a1; h.a2 = a2; h.out = out; h.ldo = 1; h.out_rows = out_rows;
+    GG_REQUIRE(head_fused_supported(h), "gg_test_head_fwd: unsupported operands");
+    return head_fwd(h, (hipStream_t)stream);
+}
+int gg_test_head_bwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* W2, const float* w3,
+                     const float* a1, const float* a2, const float* dout, float* dh2, float* dh1, float* dcond, void* stream) {
+    HeadP h;
+    h.rows = rows; h.H = H; h.E = E; h.slope = slope; h.W1c = W1c; h.ldw1 = ldw1; h.W2 = W2; h.w3 = w3;
+    h.a1 = const_cast<float*>(a1); h.a2 = const_cast<float*>(a2); h.dout = dout; h.dh2 = dh2; h.dh1 = dh1; h.dcond = dcond;
+    GG_REQUIRE(head_fused_supported(h), "gg_test_head_bwd: unsupported operands");
+    return head_bwd(h, (hipStream_t)stream);
+}
+
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,
                   int64_t fgrad_ldw, float* dgamma, float* dbeta, int64_t fgrad_ld, int fgrad_tokens, float* dbias, int64_t x_mod,

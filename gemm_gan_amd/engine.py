@@ -293,6 +293,9 @@ class Engine:
     def set_sqx(self, on: bool):
         L.check(self.lib.gg_set_sqx(self.h, int(on)))
 
+    def set_head_fused(self, on: bool):
+        L.check(self.lib.gg_set_head_fused(self.h, int(on)))
+
     def set_lnb_fused(self, on: bool):
         L.check(self.lib.gg_set_lnb_fused(self.h, int(on)))
 

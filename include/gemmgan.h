@@ -203,6 +203,7 @@ int gg_set_precision(gg_engine* e, int precision);    /* GG_PREC_* ; may be swit
 int gg_set_flash(gg_engine* e, int on);               /* fused attention kernels in bf16 mode (default on) */
 int gg_set_wgrad(gg_engine* e, int on);               /* long-reduction weight-gradient kernel in bf16 mode (default on) */
 int gg_set_bstore(gg_engine* e, int on);              /* bf16 storage of MFMA-operand-only tensors in bf16 mode (default on) */
+int gg_set_head_fused(gg_engine* e, int on);          /* MLP heads as one forward and one backward launch, bf16 mode (default off: no faster) */
 int gg_set_lnb_fused(gg_engine* e, int on);           /* dx1 += and LayerNorm-1 backward in one kernel, bf16 mode at E = 256 (default on) */
 int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the encoder's LayerNorm outputs and of the pre-LayerNorm sums kept
                                                           for the backward pass, bf16 mode at E = 256 (default 1; 0 off; 3 = outputs only) */
@@ -277,6 +278,15 @@ int gg_test_sqx_fwd(const float* qt, const float* x, const uint8_t* mask, int ma
                     int nh, void* stream);
 int gg_test_sqx_bwd(const float* dxbar, const float* qt, const float* xbar, const float* x, const float* probs, float* dx, float* dqt,
                     int N, int S, int E, int nh, void* stream);
+/* fused MLP head (csrc/head.hip; R:226-231).  forward: a1 [rows,H] holds the gene / latent part of the first layer on entry and
+ * act(a1 + cvec W1c^T + b1) on return, a2 = act(a1 W2^T + b2), out[r] = a2[r] . w3 + b3 for r < out_rows (out may be null).
+ * backward: dout [rows] (score gradient; null: dh2 holds dout W3 on entry) -> dh2, dh1 [rows,H], dcond [rows,E] (may be null).
+ * W1c: [H][E] slice of the first-layer weight, row stride ldw1.  LeakyReLU(slope). */
+int gg_test_head_fwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* b1, const float* W2,
+                     const float* b2, const float* w3, const float* b3, const float* cvec, float* a1, float* a2, float* out,
+                     int64_t out_rows, void* stream);
+int gg_test_head_bwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* W2, const float* w3,
+                     const float* a1, const float* a2, const float* dout, float* dh2, float* dh1, float* dcond, void* stream);
 /* LayerNorm backward with the dropout-masked branch gradient (fp32 or bf16) and the fused bias / gamma / beta column sums;
  * dres_bf16: bit 0 = bf16 branch-gradient output, bit 1 = r is a bf16 array (E = 256 only) */
 int gg_test_ln_bwd(const float* dy, const float* r, const float* stats, const float* g, float* dr, void* dres_out, float* dgamma,

@@ -510,6 +510,50 @@ def test_fused_accumulate_layernorm_backward_matches_the_two_launch_route(dropou
     ck.done()
 
 
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
+def test_fused_mlp_head_route_matches_the_launch_per_product_route(case):
+    """head.hip (opt-in: gg_set_head_fused) inside a critic and a generator iteration against the lin_fwd / lin_bwd_data / k_act_bwd
+    chain: same bf16 operand roundings, only fp32 summation order differs (a value of a1 / dh2 / dh1 on a bf16 rounding boundary
+    may round the other way as an operand of the next product)."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    out = {}
+    for on in (False, True):
+        eng.set_head_fused(on)
+        eng.set_seed(5)
+        eng.reset_launch_count()
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        n_crit = eng.launch_count()
+        out[on] = dict(losses=eng.losses.clone(), launches=n_crit, g={k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()})
+        eng.generator_backward(z, patches, patch_pad, text, text_pad)
+        out[on]["gl"] = eng.losses.clone()
+        out[on]["gg"] = {k: v.clone() for k, v in eng.state(L.ROLE_GENERATOR, "g").items()}
+    a, b = out[True], out[False]
+    if cfg.embedding_dims % 32 == 0 and cfg.hidden_dims % 32 == 0:
+        assert a["launches"] < b["launches"], (a["launches"], b["launches"])          # the fused kernels really ran
+    ck = Checker(f"fused MLP head vs launch-per-product, {case}", 5e-3, metric="max")
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=2e-3)
+    ck.check("generator loss", a["gl"][3:4], b["gl"][3:4], tol=2e-3)
+    from test_bf16_parity_gpu import significant
+    for k in a["g"]:
+        if significant(b["g"][k]):
+            ck.check("dD " + k, a["g"][k], b["g"][k])
+    for k in a["gg"]:
+        if significant(b["gg"][k]):
+            ck.check("dG " + k, a["gg"][k], b["gg"][k], tol=5e-2)        # a flipped critic-head gate moves d(loss)/d(x_fake): see the tlin test above
+    ck.done()
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_fused_feed_forward_route_matches_the_two_launch_route(dropout):
     """ffn.hip inside a critic iteration (opt-in: gg_set_ffn_fused) against FFN1 + FFN2 as two token-on-lane Linears: same

@@ -709,6 +709,71 @@ def test_accumulate_then_layernorm_backward_kernel_equals_the_fp64_result(M, dro
     check("fused bias gradient", dbias_d, dres.sum(0), False)
 
 
+# ---- fused MLP head -------------------------------------------------------------------------------------------------------------
+def lrelu(x, slope):
+    return torch.where(x > 0, x, x * slope)
+
+
+@pytest.mark.parametrize("rows,H,E,V,slope,score", [(768, 256, 256, 5000, 0.0, True), (70, 256, 256, 64, 0.2, True), (515, 256, 256, 256, 0.2, False),
+                                                    (96, 64, 64, 40, 0.0, True), (33, 128, 32, 8, 0.2, False)])
+def test_fused_mlp_head_equals_the_fp64_chain(rows, H, E, V, slope, score):
+    """head_fwd_k / head_bwd_k (csrc/head.hip): the three-layer MLP head of R:226-231 (first layer = stored gene / latent part +
+    conditioning part) and its data-path backward, each in one launch.  Reference: float64 on operands rounded to bf16 exactly where
+    the launch-per-product route (gemm_small.hip) rounds them: every product's two operands.  Ragged row counts (clamped lanes),
+    narrow widths (waves without a tile), the first-layer weight as a column slice of [H, V + E]."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(rows + H)
+    W1 = rnd(g, H, V + E, scale=0.08)
+    b1, W2, b2 = rnd(g, H, scale=0.1), rnd(g, H, H, scale=0.08), rnd(g, H, scale=0.1)
+    w3, b3 = rnd(g, H, scale=0.1), rnd(g, 1, scale=0.1)
+    cvec, a1_pre = rnd(g, rows, E), rnd(g, rows, H)
+    d = lambda t: t.to(DEV, torch.float32).contiguous()
+    W1_d, b1_d, W2_d, b2_d, w3_d, b3_d, c_d = d(W1), d(b1), d(W2), d(b2), d(w3), d(b3), d(cvec)
+    a1_d = d(a1_pre).clone()
+    a2_d = torch.full((rows, H), float("nan"), device=DEV)
+    out_rows = (2 * rows) // 3 if score else 0
+    out_d = torch.full((rows,), float("nan"), device=DEV)
+    W1c_ptr = C.c_void_p(W1_d.data_ptr() + 4 * V)
+    L.check(lib.gg_test_head_fwd(rows, H, E, C.c_float(slope), W1c_ptr, V + E, P(b1_d), P(W2_d), P(b2_d), P(w3_d), P(b3_d), P(c_d), P(a1_d),
+                                 P(a2_d), P(out_d) if score else None, out_rows, stream()))
+    torch.cuda.synchronize()
+    W1c = W1[:, V:]
+    a1 = lrelu(a1_pre.double() + bf(cvec) @ bf(W1c).T + b1.double(), slope)
+    a2 = lrelu(bf(a1.float()) @ bf(W2).T + b2.double(), slope)
+    diag(f"== fused MLP head rows={rows} H={H} E={E} slope={slope}")
+    check("a1", a1_d, a1, False)
+    # a2's operand is the bf16 rounding of the kernel's own fp32 a1: where that sits on a rounding boundary the two runs round apart
+    check("a2", a2_d, a2, False, 2e-4, 3e-3)
+    if score:
+        out = bf(a2.float()) @ bf(w3) + b3.double()
+        got = out_d.cpu()
+        assert torch.isnan(got[out_rows:]).all(), "scores of rows past out_rows must not be written"
+        check("critic score", got[:out_rows], out[:out_rows], False, 2e-4, 3e-3)
+    # backward on the kernel's own activations
+    a1_k, a2_k = a1_d.cpu(), a2_d.cpu()
+    if score:
+        dout = rnd(g, rows, scale=0.5)
+        dout_d = d(dout)
+        dh2_d = torch.full((rows, H), float("nan"), device=DEV)
+        dh2_pre = bf(dout)[:, None] * bf(w3)[None, :]
+    else:
+        dh2_pre = rnd(g, rows, H, scale=0.5).double()
+        dh2_d = d(dh2_pre.float()).clone()
+        dout_d = None
+    dh1_d = torch.full((rows, H), float("nan"), device=DEV)
+    dc_d = torch.full((rows, E), float("nan"), device=DEV)
+    L.check(lib.gg_test_head_bwd(rows, H, E, C.c_float(slope), W1c_ptr, V + E, P(W2_d), P(w3_d), P(a1_d), P(a2_d), P(dout_d), P(dh2_d), P(dh1_d),
+                                 P(dc_d), stream()))
+    torch.cuda.synchronize()
+    gate = lambda a: torch.where(a.double() > 0, torch.ones_like(a, dtype=torch.float64), torch.full_like(a, slope, dtype=torch.float64))
+    dh2 = dh2_pre * gate(a2_k)
+    dh1 = (bf(dh2.float()) @ bf(W2)) * gate(a1_k)
+    dc = bf(dh1.float()) @ bf(W1c)
+    check("dh2", dh2_d, dh2, False)
+    check("dh1", dh1_d, dh1, False, 2e-4, 3e-3)
+    check("dcond", dc_d, dc, False, 2e-4, 3e-3)
+
+
 # ---- fused feed-forward block ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,keep_rows,drop_on", [(8 * 257, -1, True), (8 * 257, 3 * 257, True), (5 * 257 + 3, 0, False), (70000, 1000, True)])
 def test_fused_feed_forward_block_equals_the_fp64_result(M, keep_rows, drop_on):
