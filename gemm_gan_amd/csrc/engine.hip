@@ -1914,7 +1914,7 @@ int critic_cond_prefetch(Ctx& c, const gg_cond* in) {
 extern "C" {
 
 const char* gg_last_error(void) { return gg::g_err.c_str(); }
-const char* gg_version(void) { return "gemm_gan_amd 0.2 (gfx950: bf16-MFMA engine, f32-MFMA parity mode)"; }
+const char* gg_version(void) { return "gemm_gan_amd 0.3 (gfx950: bf16-MFMA engine, bf16x3 split-operand and f32-MFMA parity modes)"; }
 
 int gg_create(const gg_config* cfg, gg_engine** out) {
     GG_REQUIRE(cfg && out, "null argument");
