@@ -401,16 +401,23 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 2 : 1) void wgrad_kernel(const
         f32x4 sv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(&sl[8 * g + 4 * h]);
-        const float* wb = fg.W + (long)(n0 + nb + 4 * h) * fg.ldw + k0 + kb + c;
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             float vg = 0.f, vb = 0.f;
             const bool colok = kb + b * 32 + c < kvalid;
+            // the 16 weights of this lane's column: unconditional loads from clamped addresses, all in flight together (with
+            // `ok ? load : 0` per element the compiler waited for every one of the 64 loads where it was issued: vmcnt(0) each)
+            const int colc = min(k0 + kb + b * 32 + c, K - 1);
+            float wv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2);
-                const bool ok = colok && nb + 4 * h + rr < nvalid;
-                const float w = ok ? wb[(long)rr * fg.ldw + b * 32] : 0.f;
+                wv[i] = fg.W[(long)min(n0 + nb + 4 * h + rr, N - 1) * fg.ldw + colc];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2);
+                const float w = (colok && nb + 4 * h + rr < nvalid) ? wv[i] : 0.f;
                 vg += acc[0][b][i] * w;
                 vb += sv[i >> 2][i & 3] * w;
             }
