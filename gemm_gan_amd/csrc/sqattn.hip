@@ -310,23 +310,32 @@ __global__ __launch_bounds__(TPB, 2) void sqx2_fwd_kernel(const float* __restric
         for (int k = 0; k < NV; ++k) acc[h][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nit = (S + 15) / 16;
+    // The next row (and its mask byte) is requested UNCONDITIONALLY from a clamped index: `if (it + 1 < nit) load` and `mrow &&
+    // mrow[r]` made the wait-count pass drain the request at once (vmcnt(0)) - the row prefetch did not exist and every iteration
+    // paid for a mask-byte round trip.  Without a mask the byte is read from the x rows (any valid address) and ignored.
+    const bool use_mask = mrow != nullptr;
+    const uint8_t* mr = use_mask ? mrow : reinterpret_cast<const uint8_t*>(x);
     f32x4 nxt[NV];
+    uint8_t mnxt;
     {
         const int r0 = min(4 * wave + slot, S - 1);
 #pragma unroll
         for (int k = 0; k < NV; ++k) nxt[k] = *reinterpret_cast<const f32x4*>(xn + (long)r0 * E + 64 * k);
+        mnxt = mr[r0];
     }
     for (int it = 0; it < nit; ++it) {
         const int r = 16 * it + 4 * wave + slot;
         f32x4 cur[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) cur[k] = nxt[k];
-        if (it + 1 < nit) {
+        const uint8_t mcur = mnxt;
+        {
             const int rn = min(r + 16, S - 1);
 #pragma unroll
             for (int k = 0; k < NV; ++k) nxt[k] = *reinterpret_cast<const f32x4*>(xn + (long)rn * E + 64 * k);
+            mnxt = mr[rn];
         }
-        const bool valid = r < S && !(mrow && mrow[r]);
+        const bool valid = r < S && !(use_mask && mcur);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             float d = 0.f;

@@ -851,7 +851,7 @@ __global__ void shadow_kernel(const float* __restrict__ w, __bf16* __restrict__ 
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + ty + 8 * k, c = c0 + tx;
             const bool in = r < e.rows && c < e.cols;
-            const float v = in ? w[e.off + (long)r * e.cols + c] : 0.f;
+            const float v = w[e.off + (long)min(r, e.rows - 1) * e.cols + min(c, e.cols - 1)];      // unconditional (clamped): the four loads fly together
             t[ty + 8 * k][tx] = v;
             if (in) wb[e.off + (long)r * e.cols + c] = (__bf16)v;
         }
@@ -876,7 +876,7 @@ __global__ void shadow_t32_kernel(const float* __restrict__ w, float* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + ty + 8 * k, c = c0 + tx;
-            t[ty + 8 * k][tx] = (r < e.rows && c < e.cols) ? w[e.off + (long)r * e.cols + c] : 0.f;
+            t[ty + 8 * k][tx] = w[e.off + (long)min(r, e.rows - 1) * e.cols + min(c, e.cols - 1)];
         }
         __syncthreads();
 #pragma unroll
