@@ -1119,7 +1119,7 @@ int k_shadow_weights_t32(const float* w, float* wt, const ShadowEntry* tab_dev, 
 
 int k_shadow_weights(const float* w, void* wb, void* wtb, const ShadowEntry* tab_dev, int n_entries, hipStream_t st) {
     if (n_entries <= 0) return 0;
-    shadow_kernel<<<dim3(64, n_entries), 256, 0, st>>>(w, reinterpret_cast<__bf16*>(wb), reinterpret_cast<__bf16*>(wtb), tab_dev);
+    shadow_kernel<<<dim3(256, n_entries), 256, 0, st>>>(w, reinterpret_cast<__bf16*>(wb), reinterpret_cast<__bf16*>(wtb), tab_dev);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
