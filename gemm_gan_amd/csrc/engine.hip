@@ -1644,9 +1644,12 @@ int gp_chain(Ctx& c, Net& D, const float* a1h, const float* a2h, int B, float* g
         p.layA = LAY_KC; p.layB = LAY_KC;
         const long tiles = tiles_of(B, H);
         p.splitk = (int)std::max<long>(2, std::min<long>((G + 255) / 256, std::max<long>(1, 256 / tiles)));
-        // exact fp32 in both modes (see gpchain.hip)
+        // fp32-grade in every mode (see gpchain.hip): six bf16 part products on the register-direct 32 x 32 kernel (1 280 workgroups,
+        // every operand fragment in flight at once) when the operands are aligned for it, the exact fp32-input tile GEMM otherwise
         e->launches++;
-        GG_TRY(gemm_f32(p, c.st));
+        static const bool f32_only = getenv("GG_GP_DG1_F32") != nullptr;
+        if (!f32_only && e->precision == GG_PREC_BF16 && gemm_small_x3_ok(p)) GG_TRY(gemm_small_x3(p, c.st));
+        else GG_TRY(gemm_f32(p, c.st));
     }
     {   // dW2, dw3: on the side stream like the head's own dW2 / dW3 (they add into the same gradient slots)
         Ctx cs = c;
