@@ -372,7 +372,7 @@ int gemm_small_x3(const GemmP& p, hipStream_t st) {
 bool gemm_small_wanted(const GemmP& p) {
     if (p.film_gamma || p.a_bf16 || p.b_bf16) return false;
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    static const long cap = getenv("GG_SMALL_MAX") ? atol(getenv("GG_SMALL_MAX")) : 128;
+    static const long cap = getenv("GG_SMALL_MAX") ? atol(getenv("GG_SMALL_MAX")) : 256;      // (256: the gene-dimension products of the critic head, 36 -> 31 and 46 -> 31 us)
     return tiles128 * p.splitk <= cap;                 // would not fill the chip with 128x128 tiles anyway
 }
 
