@@ -49,6 +49,7 @@ struct Net {
     char *wb = nullptr, *wtb = nullptr;
     char *wp3 = nullptr, *wtp3 = nullptr;     // bf16x3 mode: three bf16 parts (hi, mid, lo) of W / W^T, part sp at + 2 * total * sp bytes
     // fp8 mode: e4m3 shadow of the same weights (tensor at byte offset 2 * flat offset), per-tensor exponents
+    char* wfrag = nullptr;                    // fragment-ordered bf16 image of linear1 / linear2 of every encoder layer (enc.hip: the fused feed-forward stream)
     char* w8 = nullptr;
     unsigned* w8_amax = nullptr;
     int* w8_exp = nullptr;
@@ -188,6 +189,7 @@ struct gg_engine {
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
+    int ffn2_on = getenv("GG_FFN2") ? atoi(getenv("GG_FFN2")) : 0;     // 1 + variant: the streamed fused feed-forward block (enc.hip) in bf16 mode with bf16-stored LayerNorm outputs
     int ffn_on = getenv("GG_FFN_FUSED") != nullptr;   // fused feed-forward block (ffn.hip), bf16 mode, E = 256: opt-in (or gg_set_ffn_fused) -
                                // measured 20 % slower than the two launches it replaces (profiles/r03_ffn_fused.md)
     float *s_dt, *s_dp, *s_dq, *s_dq2, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
@@ -413,6 +415,7 @@ size_t carve(gg_engine* e, void* base) {
         n.w8 = a.take<char>((size_t)n.total * 2);
         n.w8_amax = a.take<unsigned>(n.tab.size() + 1);
         n.w8_exp = a.take<int>(n.tab.size() + 1);
+        n.wfrag = a.take<char>(enc_frag_bytes(e->nl));
     }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
@@ -645,6 +648,11 @@ int refresh_shadows(Ctx& c, Net& n) {
         return 0;
     }
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
+    if (c.e->ffn2_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {
+        long o1[MAXL], o2[MAXL];
+        for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; }
+        KL(k_enc_frag_weights(n.w, o1, o2, c.e->nl, n.wfrag, c.st));
+    }
     if (c.e->fp8_fwd) {
         GG_TRY(k_shadow_weights_fp8(n.w, n.w8, n.w8_amax, n.w8_exp, n.tab_dev, (int)n.tab.size(), c.st));
         c.e->launches += 2;
@@ -957,6 +965,19 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 const double tokd = (double)RB * S, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
                 ProfScope ps(c, "ffn_fused_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (4.0 * E + 4.0 * E) + kept * (2.0 * F + 4.0 * E) + 4.0 * E * F);
                 KL(ffn_fused(f, c.st));
+                ffn_done = true;
+            }
+        }
+        if (!ffn_done && xst && rst && !e->fp8_fwd && e->ffn2_on && E == 256 && F == 512) {   // the streamed form (enc.hip): bf16 x1 in, weights as MFMA fragments through an LDS ring
+            Ffn2P f;
+            f.X = L.x1; f.M = RB * S; f.Wf = n.wfrag + (size_t)l * enc_frag_bytes(1);
+            f.b1 = w + lp.l1b; f.b2 = w + lp.l2b; f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b;
+            f.Hs = L.h; f.R2 = L.r2; f.r2_bf16 = 1; f.stats = L.st2; f.Y = L.x2; f.y_bf16 = l + 1 < e->nl; f.keep_rows = keep_rows;
+            f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
+            if (ffn2_supported(f) && (f.drop1.p > 0.f) == (f.drop2.p > 0.f)) {
+                const double tokd = (double)RB * S, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
+                ProfScope ps(c, "ffn2_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (2.0 * E + (f.y_bf16 ? 2.0 : 4.0) * E) + kept * (2.0 * F + 2.0 * E + 8.0) + 4.0 * E * F);
+                KL(ffn2(f, c.st, e->ffn2_on - 1));
                 ffn_done = true;
             }
         }
@@ -2188,7 +2209,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21 | (uint64_t)e->head_on << 22,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21 | (uint64_t)e->head_on << 22 | (uint64_t)e->ffn2_on << 23,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2327,6 +2348,13 @@ int gg_set_prefetch(gg_engine* e, int on) {
 int gg_set_flash(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->flash = on != 0;
+    return 0;
+}
+int gg_set_ffn2(gg_engine* e, int mode) {
+    GG_REQUIRE(e, "null engine");
+    GG_REQUIRE(mode == 0 || mode == 1 || mode == 3, "gg_set_ffn2: 0 off, 1 / 3 on (4- / 8-slot weight ring)");
+    e->ffn2_on = mode;
+    drop_graphs(e);
     return 0;
 }
 int gg_set_ffn_fused(gg_engine* e, int on) {

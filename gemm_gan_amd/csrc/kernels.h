@@ -168,6 +168,29 @@ bool ffn_fused_supported(const FfnP& p);
 int ffn_fused(const FfnP& p, hipStream_t st);
 void ffn_time_next(hipEvent_t begin, hipEvent_t end);
 
+// fused feed-forward block, round 4 (enc.hip): same arithmetic and dropout streams as FFN1 + FFN2 of the weight-stationary route with bf16-stored
+// LayerNorm outputs: X = x1 (bf16, input and residual), weights as a fragment-ordered bf16 stream (k_enc_frag_weights), h (bf16) / r2 (bf16 or
+// fp32) / statistics stored for rows < keep_rows only (-1: all), Y = x2 (bf16 or fp32) for every row
+struct Ffn2P {
+    const void* X = nullptr; long M = 0;            // bf16 [M, 256]
+    const void* Wf = nullptr;                       // this layer's fragment stream (enc_frag_bytes(1) bytes)
+    const float* b1 = nullptr; const float* b2 = nullptr; const float* ln_g = nullptr; const float* ln_b = nullptr;
+    void* Hs = nullptr;                             // bf16 [M, 512]
+    void* R2 = nullptr; int r2_bf16 = 0;            // pre-LayerNorm sum [M, 256]
+    float* stats = nullptr;                         // [M, 2] (mean, rstd)
+    void* Y = nullptr; int y_bf16 = 0;              // [M, 256]
+    long keep_rows = -1;
+    DropKey drop1, drop2;                           // inner (element index = token * 512 + f) and post-FFN (token * 256 + n) dropout
+    unsigned* stamps = nullptr;                     // tools/ffn2_probe.py: per-phase cycle sums, [workgroups * waves][8]
+};
+bool ffn2_supported(const Ffn2P& p);
+// variant: 0 = 4-slot weight ring (64 KB), 2 = 8-slot ring (128 KB)
+int ffn2(const Ffn2P& p, hipStream_t st, int variant = 0);
+void ffn2_time_next(hipEvent_t begin, hipEvent_t end);
+size_t enc_frag_bytes(int nl);                      // bytes of the fragment-ordered image of nl layers
+// out[layer] = fragment stream of linear1.weight [512][256] at w + w1_off[layer] and linear2.weight [256][512] at w + w2_off[layer]
+int k_enc_frag_weights(const float* w, const long* w1_off, const long* w2_off, int nl, void* out, hipStream_t st);
+
 // split-operand (bf16x3) attention of GG_PREC_BF16X3: fp32 qkv / ctx / dctx / dqkv, `ns` bf16 parts per MFMA operand (2: three
 // products per tile - the backward form; 3: six products, fp32-grade - the forward form); any S <= 2048 (keys / queries streamed)
 bool flash_attn_x3_supported(int S, int E, int nh);

@@ -92,6 +92,27 @@ int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1
     return ffn_fused(f, (hipStream_t)stream);
 }
 
+// fused feed-forward block of round 4 (enc.hip): the fragment-ordered weight image is built from the fp32 weights into `wfrag`
+// (gg_test_ffn2_frag_bytes() bytes) exactly as refresh_shadows does, then the kernel runs as in cond_forward
+int64_t gg_test_ffn2_frag_bytes(void) { return (int64_t)enc_frag_bytes(1); }
+int gg_test_ffn2(const void* X, int64_t M, const float* W1, const float* b1, const float* W2, const float* b2, void* Hs, void* R2, int r2_bf16,
+                 int64_t keep_rows, const float* ln_g, const float* ln_b, void* Y, int y_bf16, float* stats, float drop_p, uint64_t drop_seed,
+                 uint32_t site1, uint32_t site2, uint32_t drop_call, void* wfrag, int variant, void* stream) {
+    GG_REQUIRE(X && W1 && W2 && wfrag, "null argument");
+    unsigned* stamps = nullptr;
+    if (variant >= 64) { stamps = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(wfrag) + enc_frag_bytes(1)); variant -= 64; }   // probe: + 256 * 8 * 8 words behind the image
+    const long o1 = 0, o2 = W2 - W1;
+    GG_TRY(k_enc_frag_weights(W1, &o1, &o2, 1, wfrag, (hipStream_t)stream));
+    Ffn2P f;
+    f.X = X; f.M = M; f.Wf = wfrag; f.b1 = b1; f.b2 = b2; f.ln_g = ln_g; f.ln_b = ln_b; f.Hs = Hs; f.R2 = R2; f.r2_bf16 = r2_bf16;
+    f.stats = stats; f.Y = Y; f.y_bf16 = y_bf16; f.keep_rows = keep_rows;
+    f.drop1 = make_drop_key(drop_p, drop_seed, site1, drop_call);
+    f.drop2 = make_drop_key(drop_p, drop_seed, site2, drop_call);
+    f.stamps = stamps;
+    GG_REQUIRE(ffn2_supported(f), "gg_test_ffn2: unsupported operands");
+    return ffn2(f, (hipStream_t)stream, variant);
+}
+
 int gg_test_head_fwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* b1, const float* W2,
                      const float* b2, const float* w3, const float* b3, const float* cvec, float* a1, float* a2, float* out,
                      int64_t out_rows, void* stream) {

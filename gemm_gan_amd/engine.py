@@ -302,6 +302,10 @@ class Engine:
     def set_xstore(self, on: bool):
         L.check(self.lib.gg_set_xstore(self.h, int(on)))
 
+    def set_ffn2(self, mode: int):
+        """Streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring)."""
+        L.check(self.lib.gg_set_ffn2(self.h, int(mode)))
+
     def set_ffn_fused(self, on: bool):
         L.check(self.lib.gg_set_ffn_fused(self.h, int(on)))
 

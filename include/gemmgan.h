@@ -209,6 +209,7 @@ int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the enc
                                                           for the backward pass, bf16 mode at E = 256 (default 1; 0 off; 3 = outputs only) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
+int gg_set_ffn2(gg_engine* e, int mode);               /* streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring); needs the bf16-stored LayerNorm outputs */
 int gg_set_ffn_fused(gg_engine* e, int on);           /* fused feed-forward block (one launch per layer) in bf16 mode at E = 256 (default off: measured slower than the two launches) */
 int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
 int gg_get_optimizer_step(const gg_engine* e, int role); /* Adam/AdamW bias-correction step count   */
@@ -268,6 +269,12 @@ int gg_test_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const f
 int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1, const void* W2T, const float* b2, void* Hs, float* R2,
                       int64_t keep_rows, const float* ln_g, const float* ln_b, float* Y, float* stats, float drop_p, uint64_t drop_seed,
                       uint32_t site1, uint32_t site2, uint32_t drop_call, void* stream);
+/* fused feed-forward block, round 4 (csrc/enc.hip): X = x1 as bf16 [M,256]; W1 [512,256] / W2 [256,512] fp32 (the fragment-ordered bf16 image is
+   built into wfrag, gg_test_ffn2_frag_bytes() bytes); Hs bf16 [M,512], R2 bf16 or fp32 [M,256], stats [M,2] for rows < keep_rows; Y bf16 or fp32 */
+int64_t gg_test_ffn2_frag_bytes(void);
+int gg_test_ffn2(const void* X, int64_t M, const float* W1, const float* b1, const float* W2, const float* b2, void* Hs, void* R2, int r2_bf16,
+                 int64_t keep_rows, const float* ln_g, const float* ln_b, void* Y, int y_bf16, float* stats, float drop_p, uint64_t drop_seed,
+                 uint32_t site1, uint32_t site2, uint32_t drop_call, void* wfrag, int variant, void* stream);
 /* dW [N,K] += dY [M,N]^T X [M,K] over the token rows (+ optional FiLM on X, FiLM-gradient contraction, bias column sums) */
 int gg_test_wgrad(const void* dY, int64_t ldy, int dy_bf16, const void* X, int64_t ldx, int x_bf16, float* dW, int64_t ldw, int64_t M,
                   int N, int K, const float* film_g, const float* film_b, int64_t film_ld, int film_group, const float* fgrad_W,

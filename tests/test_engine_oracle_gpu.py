@@ -600,6 +600,55 @@ def test_fused_feed_forward_route_matches_the_two_launch_route(dropout):
     ck.done()
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_streamed_feed_forward_route_matches_the_two_launch_route(dropout, mode):
+    """enc.hip (gg_set_ffn2) inside a critic iteration against FFN1 + FFN2 as two weight-stationary Linears, default bf16 storage
+    (bf16 x1 / r2 / x2): same operands and dropout streams; only the bf16 rounding of a hidden value on a tie and the fp32 summation
+    order differ.  Every stored row is compared (h / r2 of the forward-only replica are written by neither route... by the
+    two-launch route only for h: compared on the rows both store)."""
+    c = CASES["hot_tiles_E256"]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_dropout(dropout)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    names = ["D.L0.x1", "D.L0.h", "D.L0.x2", "D.L1.x2", "D.c"]
+    out = {}
+    for on in (0, mode):
+        eng.set_ffn2(on)
+        eng.set_seed(5)
+        eng.reset_launch_count()
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(), launches=eng.launch_count(),
+                       **{n: eng.debug_buffer(n) for n in names})
+    eng.set_ffn2(0)
+    a, b = out[mode], out[0]
+    assert a["launches"] != b["launches"], (a["launches"], b["launches"])          # the fused kernel really ran (one launch less per layer, one more per shadow refresh)
+    ck = Checker(f"streamed feed-forward vs two launches, dropout={dropout}, mode={mode}", 6e-3, metric="max")
+    R_ = 3 if dropout > 0 else 1
+    S_, F_ = P + 1, 2 * cfg.embedding_dims
+    kept = (2 if R_ == 3 else 1) * B * S_
+    for n in names:
+        u, v = a[n].float(), b[n].float()
+        if n.endswith(".h"):
+            u, v = u.view(-1, F_)[:kept], v.view(-1, F_)[:kept]
+        ck.check(n, u, v)
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=1e-2)
+    cs = _cos(a["g"], b["g"])
+    from gpu_util import diag
+    diag(f"   flat critic gradient cosine streamed vs two launches: {cs:.6f}")
+    assert cs > 0.999, cs
+    ck.done()
+
+
 @pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
 def test_bf16_operand_storage_is_numerically_transparent(case):
     """Storing the MFMA-operand-only tensors (qkv, attention context, FFN hidden and the matching branch

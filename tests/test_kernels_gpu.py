@@ -825,3 +825,80 @@ def test_fused_feed_forward_block_equals_the_fp64_result(M, keep_rows, drop_on):
         check("LayerNorm statistics", st_d[:kr].cpu(), torch.cat([mu, rstd], 1)[:kr], False)
     if kr < M:
         assert torch.isnan(h_d[kr:].float()).all() and torch.isnan(r2_d[kr:]).all() and torch.isnan(st_d[kr:]).all()
+
+
+# ---- fused feed-forward block, round 4 (csrc/enc.hip) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [0, 2, 4, 6])
+@pytest.mark.parametrize("M,keep_rows,drop_on,r2_bf16,y_bf16", [
+    (8 * 257, -1, True, 1, 1), (8 * 257, 3 * 257, True, 1, 0), (5 * 257 + 3, 0, False, 0, 0), (33, -1, True, 0, 1),
+    (70000, 1024, True, 1, 1), (768 * 257, 512 * 257, True, 1, 1)])
+def test_fused_feed_forward_stream_kernel_equals_the_fp64_result(M, keep_rows, drop_on, r2_bf16, y_bf16, variant):
+    """ffn2_kernel (csrc/enc.hip): x2 = LN(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch with the weights streamed as MFMA
+    fragments through an LDS ring (LDS-DMA, counted waits).  x1 is the bf16-stored LayerNorm output (operand AND residual), h is
+    rounded to bf16 (stored and multiplied as bf16), r2 / x2 are stored in bf16 or fp32.  Rows >= keep_rows: h / r2 / statistics
+    untouched.  M = 70 000 and 768 * 257: several sweeps per workgroup, a partial last sweep, a ragged last unit; M = 33: two units,
+    one of them a single row."""
+    if M > 100000 and variant != 0:
+        pytest.skip("full-size case once")
+    lib = L.load()
+    E, F = 256, 512
+    g = torch.Generator().manual_seed(M + 11)
+    x1 = bf(rnd(g, M, E)).float()
+    W1, b1 = bf(rnd(g, F, E, scale=0.06)).float(), rnd(g, F, scale=0.1)
+    W2, b2 = bf(rnd(g, E, F, scale=0.05)).float(), rnd(g, E, scale=0.1)
+    gam, bet = 1 + rnd(g, E, scale=0.1), rnd(g, E, scale=0.1)
+    drop = (0.1, 31, 1012, 1013, 4) if drop_on else (0.0, 0, 0, 0, 0)
+    d = lambda t, dt=torch.float32: t.to(DEV, dt).contiguous()
+    x_d = d(x1, torch.bfloat16)
+    Wcat = d(torch.cat([W1.reshape(-1), W2.reshape(-1)]))          # W2 follows W1 in one buffer (the hook takes offsets from W1)
+    W1_d, W2_d = Wcat[:F * E], Wcat[F * E:]
+    b1_d, b2_d, g_d, bt_d = d(b1), d(b2), d(gam), d(bet)
+    h_d = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    r2_d = torch.full((M, E), float("nan"), dtype=torch.bfloat16 if r2_bf16 else torch.float32, device=DEV)
+    y_d = torch.full((M, E), float("nan"), dtype=torch.bfloat16 if y_bf16 else torch.float32, device=DEV)
+    st_d = torch.full((M, 2), float("nan"), device=DEV)
+    wf = torch.empty(lib.gg_test_ffn2_frag_bytes(), dtype=torch.uint8, device=DEV)
+    L.check(lib.gg_test_ffn2(P(x_d), M, P(W1_d), P(b1_d), P(W2_d), P(b2_d), P(h_d), P(r2_d), r2_bf16, keep_rows, P(g_d), P(bt_d), P(y_d), y_bf16,
+                             P(st_d), C.c_float(drop[0]), drop[1], drop[2], drop[3], drop[4], P(wf), variant, stream()))
+    torch.cuda.synchronize()
+    ks = keep_scale(drop[0]) if drop_on else 1.0
+    chunk = 16384
+    diag(f"== fused feed-forward stream kernel M={M} keep_rows={keep_rows} dropout={drop_on} r2_bf16={r2_bf16} y_bf16={y_bf16} variant={variant}")
+    kr = M if keep_rows < 0 else keep_rows
+    W1d, W2d = W1.double(), W2.double()
+    worst = {}
+    for r0 in range(0, M, chunk):           # row blocks: the float64 reference of 197 376 x 512 would not fit comfortably in one piece
+        r1 = min(M, r0 + chunk)
+        xb = x1[r0:r1].double()
+        h = (xb @ W1d.T + b1.double()).clamp_min(0)
+        if drop_on:
+            k0, thr = drop_key(drop[0], drop[1], drop[2], drop[4])
+            h = h * torch.from_numpy(drop_keep(k0, thr, np.arange(r0 * F, r1 * F, dtype=np.int64)).reshape(r1 - r0, F)).double() * ks
+        hb = bf(h.float())
+        y = hb @ W2d.T + b2.double()
+        if drop_on:
+            k0, thr = drop_key(drop[0], drop[1], drop[3], drop[4])
+            y = y * torch.from_numpy(drop_keep(k0, thr, np.arange(r0 * E, r1 * E, dtype=np.int64)).reshape(r1 - r0, E)).double() * ks
+        r2 = xb + y
+        mu = r2.mean(-1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((r2 - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+        x2 = (r2 - mu) * rstd * gam.double() + bet.double()
+        def acc(name, got, want, bfo, l2b=None, mxb=None):
+            got = got.detach().cpu()
+            assert torch.isfinite(got.float()).all(), (name, r0)
+            l2, mx = rel_l2(got, want), rel_max(got, want)
+            w = worst.setdefault(name, [0.0, 0.0])
+            w[0], w[1] = max(w[0], l2), max(w[1], mx)
+            assert l2 <= (l2b or (2e-3 if bfo else 1e-4)) and mx <= (mxb or (2.0 ** -8 if bfo else 2e-4)), (name, r0, l2, mx)
+        # (an h element within fp32 accumulation noise of a bf16 rounding boundary rounds the other way than the float64 reference:
+        # one such element moves an output by 2^-8 |h w2| ~ 2e-4 of the row scale - hence the max-norm bound of 2e-3 beside rel-L2 1e-4)
+        acc("x2 = LayerNorm(r2)", y_d[r0:r1], x2, bool(y_bf16), None, 2.0 ** -7 if y_bf16 else 2e-3)
+        ka, kb = r0, min(r1, kr)
+        if kb > ka:
+            acc("hidden activations (stored rows)", h_d[ka:kb], h[: kb - ka], True)
+            acc("pre-LayerNorm sum (stored rows)", r2_d[ka:kb], r2[: kb - ka], bool(r2_bf16), None, 2.0 ** -7 if r2_bf16 else 2e-3)
+            acc("LayerNorm statistics", st_d[ka:kb], torch.cat([mu, rstd], 1)[: kb - ka], False)
+    for k, v in worst.items():
+        diag(f"   {k:44s} rel-L2 {v[0]:.2e}  max-norm {v[1]:.2e}")
+    if kr < M:
+        assert torch.isnan(h_d[kr:].float()).all() and torch.isnan(r2_d[kr:].float()).all() and torch.isnan(st_d[kr:]).all()
