@@ -2549,6 +2549,7 @@ int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel) 
         if (s == "headD.a2") return ret(e->headD.a2, 3 * B * H);
         if (s == "headD.out") return ret(e->headD.out, 2 * B);
         if (s == "headG.a1") return ret(e->headG.a1, B * H);
+        if (s == "headG.a2") return ret(e->headG.a2, B * H);
         if (s == "gp_grad") return ret(e->gp_grad, B * G);
         if (s == "gp_nrm2") return ret(e->gp_nrm2, B);
         if (s == "gp_coef") return ret(e->gp_coef, B);

@@ -151,39 +151,44 @@ def test_replica_stacked_passes_vs_autograd(case):
     ck.done()
 
 
-def test_full_size_properties_cfg3():
-    """BASELINE cfg3 (B=256, G=5000, P=256, Dp=1024, T=1, Dt=512): size-independent properties.
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_full_size_properties_cfg3(mode):
+    """BASELINE cfg3 (B=256, G=5000, P=256, Dp=1024, T=1, Dt=512): size-independent properties, in every arithmetic mode the bench
+    quotes (f32: the exact reference; bf16x3: `parity_mode`; bf16: the headline).
     (1) critic score is independent of the batch composition (row b of a half batch == row b of the
     full batch); (2) data-parallel identity: the gradient of the full batch equals the mean of the two
-    half-batch gradients; (3) everything finite; (4) GP gradient norm matches the row norm of grad_x_hat."""
+    half-batch gradients; (3) everything finite; (4) GP gradient norm matches the row norm of grad_x_hat.
+    Bounds: f32 / bf16x3 1e-5 and 2e-4 (fp32 accumulation order); bf16 1e-3 (bf16 operand products whose split over workgroups
+    depends on the row count: accumulation order of 8-bit-mantissa terms)."""
     cfg = PathConfig(dropout=0.0)
     B, P, T = 256, 256, 1
     torch.manual_seed(3)
     tr = Trainer(cfg)
-    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.0, precision=mode)
+    t_row, t_dp = (1e-3, 1e-3) if mode == "bf16" else (1e-5, 2e-4)
     load_oracle_state(eng, tr)
     x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=9, pad_patches=True))
     g = torch.Generator().manual_seed(1)
     z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
     alpha = torch.rand(B, generator=g).cuda()
-    ck = Checker("full-size cfg3 properties", 1e-3, metric="max")
+    ck = Checker(f"full-size cfg3 properties ({mode})", 1e-3, metric="max")
     full = eng.forward(L.ROLE_CRITIC, x, patches, patch_pad, text, text_pad, train=False)
     h = B // 2
     half = eng.forward(L.ROLE_CRITIC, x[h:].contiguous(), patches[h:].contiguous(), patch_pad[h:].contiguous(),
                        text[h:].contiguous(), text_pad[h:].contiguous(), train=False)
     assert torch.isfinite(full).all()
-    ck.check("critic rows independent of batch", half, full[h:], tol=1e-5)
+    ck.check("critic rows independent of batch", half, full[h:], tol=t_row)
     eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
     gfull = eng.flat[L.ROLE_CRITIC]["g"].clone()
     nrm = eng.debug_buffer("gp_grad").view(B, -1).norm(dim=1)
     ck.check("|grad_x_hat| vs gp_nrm2", nrm ** 2, eng.debug_buffer("gp_nrm2"), tol=1e-5)
-    assert torch.isfinite(gfull).all()
+    assert torch.isfinite(gfull).all() and torch.isfinite(eng.losses).all()
     acc = torch.zeros_like(gfull)
     for s in (slice(0, h), slice(h, B)):
         eng.critic_backward(x[s].contiguous(), z[s].contiguous(), alpha[s].contiguous(), patches[s].contiguous(),
                             patch_pad[s].contiguous(), text[s].contiguous(), text_pad[s].contiguous())
         acc += eng.flat[L.ROLE_CRITIC]["g"]
-    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=2e-4)
+    ck.check("DP identity: mean of shard grads == full-batch grad", acc / 2, gfull, tol=t_dp)
     ck.done()
 
 
@@ -364,9 +369,10 @@ def test_flash_attention_matches_unfused_path(case, dropout):
     ck.done()
 
 
+@pytest.mark.parametrize("xstore", [True, False])
 @pytest.mark.parametrize("case", ["hot_tiles_E256", "mid_T5_ragged"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
-def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
+def test_token_on_lane_linear_matches_tile_gemm(case, dropout, xstore):
     """tlin.hip (activations register-resident, fused bias/ReLU/dropout/residual/LayerNorm/mask epilogues)
     against the generic tile GEMM + separate row kernels, both in bf16 mode: the operands are rounded to
     the same bf16 values and the dropout hash is indexed identically, so only the fp32 summation order
@@ -381,6 +387,10 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     load_oracle_state(eng, tr)
     eng.set_dropout(dropout)
     eng.set_precision("bf16")
+    # xstore: bf16 storage of the encoder's LayerNorm outputs and pre-LayerNorm sums (the default at the production width).  With it OFF the
+    # round-2 gates apply unchanged (activations 2e-3, gradient cosine 0.999): the looser ones below are for the extra rounding only
+    eng.set_xstore(xstore)
+    xs = xstore and cfg.embedding_dims == 256
     x, text, text_pad, patches, patch_pad = dev(*batch)
     g = torch.Generator().manual_seed(5)
     z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
@@ -405,20 +415,17 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     S_, F_ = P + 1, 2 * cfg.embedding_dims
     for n in names:
         # qkv / h are stored in bf16 on the tlin path (2^-9 element rounding), fp32 on the tile-GEMM path
-        u, v = a[n], b[n]
-        if n.endswith(".h") and dropout > 0:
-            # the hidden activations of the forward-only replica (the third of the critic's three) are not stored by the fused
-            # feed-forward kernel: no backward pass reads them
-            u, v = u.view(-1, F_)[: 2 * B * S_], v.view(-1, F_)[: 2 * B * S_]
-        # x1 / x2 (all but the last layer's) are bf16-stored too at the production width (one 2^-9 rounding; the rounded residual moves
-        # the last layer's fp32 output and the conditioning vector by a little over 2e-3 of their largest element)
-        ck.check(n, u, v, tol=6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx", "x1", "x2", "c") else None)
+        u, v = a[n], b[n]          # every row: the two-launch feed-forward route stores the forward-only replica's hidden rows too
+        # x1 / x2 (all but the last layer's) are bf16-stored too at the production width when xstore is on (one 2^-9 rounding; the rounded
+        # residual moves the last layer's fp32 output and the conditioning vector by a little over 2e-3 of their largest element)
+        loose = ("qkv", "h", "ctx", "x1", "x2", "c") if xs else ("qkv", "h", "ctx")
+        ck.check(n, u, v, tol=6e-3 if n.split(".")[-1] in loose else None)
     for n in gnames:
         # the critic's conditioning vector differs by ~5e-4 between the two bf16 paths (values that sit on a bf16
         # rounding boundary re-round differently); on these 6-12 sample batches that flips a few ReLU gates of
         # the critic head, which moves d(loss)/d(x_fake) and everything downstream by percents
         ck.check("generator pass " + n, a["gen:" + n], b["gen:" + n],
-                 tol=0.25 if n in ("dxfake", "dc") else (6e-3 if n.split(".")[-1] in ("qkv", "h", "ctx", "x1", "x2", "c") else None))
+                 tol=0.25 if n in ("dxfake", "dc") else (6e-3 if n.split(".")[-1] in loose else None))
     for k in a["gstate"]:
         from gpu_util import diag as _d
         _d(f"      dG {k:60s} cos {_cos(a['gstate'][k], b['gstate'][k]):.6f}")
@@ -429,7 +436,7 @@ def test_token_on_lane_linear_matches_tile_gemm(case, dropout):
     diag(f"   flat gradient cosine tlin vs generic: critic {cd:.6f} generator {cg:.6f}")
     # 0.997: with the bf16-stored LayerNorm outputs the rounded residual flips as many FFN gates again as the operand rounding does
     # (tests/test_gate_flips_gpu.py holds the gates fixed and bounds what is left at 1e-2); measured 0.9982 at dropout 0.1
-    assert cd > 0.997 and cg > 0.99, (cd, cg)
+    assert cd > (0.997 if xs else 0.999) and cg > 0.99, (cd, cg)
     ck.done()
 
 

@@ -47,10 +47,12 @@ def bf16_round(t):
     return t.float().to(torch.bfloat16).double()
 
 
+@pytest.mark.parametrize("xstore", [True, False])
 @pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
-def test_fp8_linears_equal_the_product_of_the_quantised_operands(case):
+def test_fp8_linears_equal_the_product_of_the_quantised_operands(case, xstore):
     cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
     eng.set_precision("fp8")
+    eng.set_xstore(xstore)          # off: the fp32-stored LayerNorm outputs are held to the 2e-4 gate again
     B, P = x.shape[0], patches.shape[1]
     S, E, F = P + 1, cfg.embedding_dims, 2 * cfg.embedding_dims
     xg, tg, tpg, pg, ppg = dev(x, text, text_pad, patches, patch_pad)
@@ -78,7 +80,7 @@ def test_fp8_linears_equal_the_product_of_the_quantised_operands(case):
             diag(f"   layer {l} {name:4s} max-norm error vs emulation {err:.3e}")
             # bf16-stored outputs carry one bf16 rounding (2^-9 relative per element); fp32 ones only accumulation order.  At the
             # production width x1 and the first layer's x2 are bf16-stored too (engine.hip "xst"), and the bf16 x1 is the residual of x2
-            stored_bf16 = name in ("qkv", "h") or (E == 256 and (name == "x1" or (name == "x2" and l == 0)))
+            stored_bf16 = name in ("qkv", "h") or (xstore and E == 256 and (name == "x1" or (name == "x2" and l == 0)))
             assert err <= (6e-3 if stored_bf16 else 2e-4), (l, name, err)
         x_in = x2
     diag(f"   worst {worst:.3e}")

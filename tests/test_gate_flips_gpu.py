@@ -125,3 +125,67 @@ def test_bf16_gradients_match_fp32_autograd_once_the_gate_pattern_is_held_fixed(
     l = eng.losses.tolist()
     want = np.array([forced["d_real"].item(), forced["d_fake"].item(), forced["gp"].item()])
     assert np.allclose(np.array(l[:3]), want, rtol=2e-2, atol=2e-3), (l[:3], want)
+
+
+GEN_MASKED_TOL = 1e-2
+
+
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+def test_bf16_generator_gradients_match_fp32_autograd_once_the_gate_pattern_is_held_fixed(case):
+    """The same for the GENERATOR iteration (R:425-461; VERDICT round 3, "missing" 6): its gradient runs backward through the frozen
+    critic's head (two layers of gates) into x_fake, then through the generator's own head (the H -> G output layer and two more
+    layers of gates) and its conditioning stack (encoder FFN gates).  The fp32 autograd oracle is re-run with all of those gates held
+    at the bf16 run's pattern; every significant generator gradient tensor of the bf16 run must then agree to <= 1e-2 rel-L2 (measured 7.7e-3 / 8.3e-3; four
+    layers of bf16 products in series: measured below), where the free-running oracle differs by up to tens of per cent on these
+    small batches.  A defect worth a few per cent in the generator's backward kernels (head backward through W1x / W3, the
+    replica-free conditioning backward) fails here although it passes the 0.25 free-running bound."""
+    cfg, tr, eng, (x, text, text_pad, patches, patch_pad) = setup(case)
+    B, P = x.shape[0], patches.shape[1]
+    S, F, H, nl = P + 1, 2 * cfg.embedding_dims, cfg.hidden_dims, cfg.n_layers
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g)
+    cond = (patches, patch_pad, text, text_pad)
+    xg, tg, tpg, pg, ppg, zg = dev(x, text, text_pad, patches, patch_pad, z)
+
+    eng.set_precision("bf16")
+    eng.generator_backward(zg, pg, ppg, tg, tpg)
+    enc16 = [(eng.debug_buffer(f"G.L{l}.h").view(B, S, F) > 0).cpu() for l in range(nl)]
+    g1, g2 = (eng.debug_buffer("headG.a1").view(B, H) > 0).cpu(), (eng.debug_buffer("headG.a2").view(B, H) > 0).cpu()
+    d1 = (eng.debug_buffer("headD.a1").view(3, B, H)[0] > 0).cpu()
+    d2 = (eng.debug_buffer("headD.a2").view(3, B, H)[0] > 0).cpu()
+    grads16 = {n: v.detach().cpu().clone() for n, v in eng.state(L.ROLE_GENERATOR, "g").items()}
+    loss16 = eng.losses.tolist()[3]
+
+    free = tr.generator_iteration(z, cond, apply=False)
+    layers = list(tr.gen.patches_transformer.layers)
+    saved = [(lay, lay.activation) for lay in layers]
+    gblocks, dblocks = getattr(tr.gen, "generator"), getattr(tr.disc, "discriminator")
+    saved_g, saved_d = [blk[1] for blk in gblocks], [blk[1] for blk in dblocks]
+    try:
+        for lay, m in zip(layers, enc16):
+            lay.activation = ForcedGateFn([m], 0.0)
+        gblocks[0][1], gblocks[1][1] = ForcedGate([g1], cfg.negative_slope), ForcedGate([g2], cfg.negative_slope)
+        dblocks[0][1], dblocks[1][1] = ForcedGate([d1], cfg.negative_slope), ForcedGate([d2], cfg.negative_slope)
+        forced = tr.generator_iteration(z, cond, apply=False)
+    finally:
+        for lay, act in saved:
+            lay.activation = act
+        for blk, act in zip(gblocks, saved_g):
+            blk[1] = act
+        for blk, act in zip(dblocks, saved_d):
+            blk[1] = act
+
+    diag(f"== generator iteration, bf16 run against fp32 autograd with the bf16 run's gates held fixed, {case}")
+    bad, worst_free, worst_forced = [], 0.0, 0.0
+    for n, ref in forced["grads"].items():
+        if not significant(ref) or n.endswith("in_proj_bias") or n not in grads16:
+            continue
+        e_free, e_forced = l2(grads16[n], free["grads"][n]), l2(grads16[n], ref)
+        worst_free, worst_forced = max(worst_free, e_free), max(worst_forced, e_forced)
+        flag = "" if e_forced <= GEN_MASKED_TOL else "   <-- FAIL"
+        diag(f"   dG {n:58s} rel-L2 vs free-running fp32 {e_free:.3e} -> gates held fixed {e_forced:.3e}{flag}")
+        if flag:
+            bad.append((n, e_forced))
+    diag(f"   worst: free-running {worst_free:.3e}, gates held fixed {worst_forced:.3e} (bound {GEN_MASKED_TOL:g})")
+    assert not bad, bad[:8]
+    assert np.allclose(loss16, forced["g_loss"].item(), rtol=2e-2, atol=2e-3), (loss16, forced["g_loss"].item())
