@@ -74,6 +74,11 @@ SYMBOLS = {
     "gg_critic_backward_cond": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
     "gg_critic_cond_prefetch": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
     "gg_mlp_grad_range": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gg_cond_stage_count": (C.c_int, [C.c_void_p]),
+    "gg_cond_stage_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gg_critic_backward_cond_stage": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_int, C.c_void_p]),
+    "gg_generator_backward_cond_stage": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_int, C.c_void_p]),
+    "gg_side_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gg_gradient_penalty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_int, C.c_void_p, C.c_void_p]),
     "gg_generator_backward_head": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GGCond), C.c_void_p, C.c_void_p]),
     "gg_generator_backward_cond": (C.c_int, [C.c_void_p, C.POINTER(GGCond), C.c_void_p]),
@@ -153,6 +158,9 @@ SYMBOLS = {
     "gg_reset_launch_count": (C.c_int, [C.c_void_p]),
     "gg_bind_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gg_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "gg_phase_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_phase_count": (C.c_int, [C.c_void_p]),
+    "gg_phase_read": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "gg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_profile_enable_class": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gg_profile_collect": (C.c_int, [C.c_void_p]),

@@ -3172,8 +3172,12 @@ bool flash_attn_supported(int S, int E, int nh) {
 const char* flash_attn_kernel_name(int which, int S, int E, int nh) {
     if (!flash_attn_supported(S, E, nh)) return "";
     const int dh = E / nh;
-    const bool lng = getenv("GG_ATTN_LONG") != nullptr || !short_ok(S, dh);
-    const bool strm = lng && getenv("GG_ATTN_LONG_V1") == nullptr;
+    // A/B switches: read once per process (this function runs on every attention enqueue when the profiler is on)
+    static const bool env_long = getenv("GG_ATTN_LONG") != nullptr, env_long_v1 = getenv("GG_ATTN_LONG_V1") != nullptr,
+                      env_dq_long_v1 = getenv("GG_ATTN_DQ_LONG_V1") != nullptr, env_dq1 = getenv("GG_ATTN_DQ1") != nullptr,
+                      env_dkv_v1 = getenv("GG_ATTN_DKV_V1") != nullptr;
+    const bool lng = env_long || !short_ok(S, dh);
+    const bool strm = lng && !env_long_v1;
     const int nqt = (S + 31) / 32;
     if (which == 0) {
         const int nw = rm_waves(true);
@@ -3183,15 +3187,15 @@ const char* flash_attn_kernel_name(int which, int S, int E, int nh) {
     const int nw = rm_waves(false);
     if (which == 1) {
         if (!lng && nw && rm_smem(S, dh, nw) <= 160 * 1024) return "attn_bwd_dq_rm_kernel";
-        if (strm && getenv("GG_ATTN_DQ_LONG_V1") == nullptr) return "attn_bwd_dq_stream_kernel";
+        if (strm && !env_dq_long_v1) return "attn_bwd_dq_stream_kernel";
         if (lng) return "attn_bwd_dq_long_kernel";
         const bool coop = (nqt % 4 == 1) && nqt > 1 && (S - 32 * (nqt - 1)) <= CO_MAXQ;
         const int items_q = (coop ? nqt - 1 : nqt) + (coop ? 4 : 0);
-        const bool dq2 = getenv("GG_ATTN_DQ1") == nullptr && nqt >= 2 && items_q <= 4 * DQ_SLOTS && 2 * dq2_smem(S, dh) <= 160 * 1024;
+        const bool dq2 = !env_dq1 && nqt >= 2 && items_q <= 4 * DQ_SLOTS && 2 * dq2_smem(S, dh) <= 160 * 1024;
         return dq2 ? "attn_bwd_dq2_kernel" : "attn_bwd_dq_kernel";
     }
     if (strm) return "attn_bwd_dkv_stream_kernel";
-    if (!lng && nw && getenv("GG_ATTN_DKV_V1") == nullptr && 2 * dkv_rm_smem(S, dh, 4) <= 160 * 1024) return "attn_bwd_dkv_rm_kernel";
+    if (!lng && nw && !env_dkv_v1 && 2 * dkv_rm_smem(S, dh, 4) <= 160 * 1024) return "attn_bwd_dkv_rm_kernel";
     return "attn_bwd_dkv_kernel";
 }
 

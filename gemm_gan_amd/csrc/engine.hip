@@ -214,6 +214,10 @@ struct gg_engine {
     uint32_t epoch_host = 0;
     uint64_t graph_clock = 0;
     int64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
+    // phase marks (gg_phase_enable): timing events on the caller's stream at the phase boundaries of a train step - the un-profiled timeline
+    bool phase_on = false;
+    std::vector<std::pair<const char*, hipEvent_t>> phase_marks;
+    std::vector<hipEvent_t> phase_pool;
     // live profiling
     bool prof_on = false;
     unsigned prof_mask = 0xffffffffu;      // kernel classes that get event pairs (bit = class id)
@@ -471,6 +475,18 @@ struct Ctx {
 };
 
 inline long tiles_of(long M, long N) { return ((M + 127) / 128) * ((N + 127) / 128); }
+
+inline void phase_mark(Ctx& c, const char* name) {
+    gg_engine* e = c.e;
+    if (!e->phase_on || e->capturing || e->phase_marks.size() >= 512) return;
+    if (e->phase_pool.size() <= e->phase_marks.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        e->phase_pool.push_back(ev);
+    }
+    hipEvent_t ev = e->phase_pool[e->phase_marks.size()];
+    if (hipEventRecord(ev, c.st) == hipSuccess) e->phase_marks.emplace_back(name, ev);
+}
 
 int named_class(gg_engine* e, const char* name) {
     for (size_t i = 0; i < e->named_cls.size(); ++i)
@@ -1129,9 +1145,14 @@ int side_wait(Ctx& c, int slot) {
     return 0;
 }
 
-int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* dc, int Rb) {
+// Stages (data-parallel hosts all-reduce a stage's gradient range while the next stage runs; gg_cond_stage_range): 0 = the cross-attention
+// blocks (or the CLS-row seed), 1 .. nl = encoder layers nl-1 .. 0, nl + 1 = replica fold, CLS token, patch encoder, FiLM, text encoder.
+// [s0, s1] = the stages this call runs; everything a later stage needs lives in the engine's scratch buffers and flags.
+int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* dc, int Rb, int s0 = 0, int s1 = 1 << 20) {
     gg_engine* e = c.e;
     const int B = a.B, P = a.P, T = a.T, S = P + 1, E = e->E, F = e->F, nh = e->nh, dh = e->dh;
+    const int s_tail = e->nl + 1;
+    auto in_stage = [&](int k) { return k >= s0 && k <= s1; };
     const int Dt = e->Dt, Dp = e->Dp;
     const long RB = (long)Rb * B;
     const float* w = n.w;
@@ -1143,11 +1164,13 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     const int bst = a.bst ? 1 : 0;
 
     if (e->no_cond) {        // nothing upstream of the (zero) conditioning vector; join the head's side-stream leaves
-        for (int i = 0; i < 5; ++i) GG_TRY(side_wait(c, i));
+        if (in_stage(s_tail))
+            for (int i = 0; i < 5; ++i) GG_TRY(side_wait(c, i));
         return 0;
     }
-    bool i2t_sh = false;
-    if (!e->xattn) {    // the conditioning vector was the encoder's CLS row: its gradient is the only non-zero row per sample
+    const bool i2t_sh = e->xattn && !a.i2t_t1 && a.i2t_shared && sq_attn_shared_ok(T, E, nh, Rb);
+    if (!in_stage(0)) {
+    } else if (!e->xattn) {    // the conditioning vector was the encoder's CLS row: its gradient is the only non-zero row per sample
         KL(k_fill(e->sdx, RB * S * E, 0.f, c.st));
         KL(k_copy_rows_strided_bcast(e->sdx, (long)S * E, dc, E, RB, RB, E, c.st));
     } else {
@@ -1180,7 +1203,6 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
         GG_TRY(side_end(c, fk, 3));
     }
     GG_TRY(lin_bwd_data(c, dc, E, w + n.i2t.ow, E, e->s_tmpE, E, (int)RB, E, E));
-    i2t_sh = a.i2t_shared && sq_attn_shared_ok(T, E, nh, Rb);
     GG_REQUIRE(i2t_sh || !a.i2t_shared, "shared I2T keys: backward replica count not supported");
     if (i2t_sh) KL(k_sq_attn_bwd_shared(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, B, Rb, T, E, nh, c.st));
     else KL(k_sq_attn_bwd(e->s_tmpE, a.i2t_q, a.i2t_kv, a.i2t_P, e->s_dq, e->s_dkv2, (int)RB, T, E, nh, c.st));
@@ -1285,6 +1307,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
     // ---- encoder layers, last to first ---------------------------------------------------------------
     float* dx = e->sdx;          // gradient w.r.t. the layer output (in), w.r.t. its input (out)
     for (int l = e->nl - 1; l >= 0; --l) {
+        if (!in_stage(e->nl - l)) continue;
         LayerActs& L = a.L[l];
         const LayerP& lp = n.layer[l];
         const bool shared = a.share0 && l == 0;          // layer-0 input and QKV projection exist once for all replicas
@@ -1455,6 +1478,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, e->sdqkv, 3 * E, w + lp.sa.inw, E, dx, E, (int)(RB * S), 3 * E, E, 1)));
         }
     }
+    if (!in_stage(s_tail)) return 0;
     // ---- fold replicas, CLS token, patch encoder, FiLM, text encoder ----------------------------------
     const float* dtok = e->s_dtokrep;
     if (Rb > 1) {
@@ -1698,6 +1722,7 @@ int critic_head_phase(Ctx& c, const float* x_real, const float* z, const float* 
     GG_TRY(refresh_shadows(c, D));
     KL(k_fill(losses, GG_N_LOSSES, 0.f, c.st));
     KL(k_fill(D.g, D.total, 0.f, c.st));
+    phase_mark(c, "critic: shadow refresh, zero gradients (+ wait for x_fake)");
     // x_fake = G(z) (generator frozen: no activations kept beyond this call)   R:391
     if (x_fake_pre) KL(k_copy(e->X2, x_fake_pre, (long)B * G, c.st));      // computed ahead by generator_prefetch
     else GG_TRY(generator_forward(c, z, in, e->X2, 1, 0));
@@ -1708,6 +1733,7 @@ int critic_head_phase(Ctx& c, const float* x_real, const float* z, const float* 
         e->dcond_valid = false;
         if (!have) GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
     }
+    phase_mark(c, "critic: conditioning forward (3 replicas)");
     e->crit_R = R;
     if (R == 1) KL(k_copy_rows_bcast(e->c3, e->actsD.c, 3L * B, B, E, c.st));
     else KL(k_copy(e->c3, e->actsD.c, 3L * B * E, c.st));
@@ -1724,21 +1750,22 @@ int critic_head_phase(Ctx& c, const float* x_real, const float* z, const float* 
     GG_TRY(head_backward(c, D, e->dseed, e->X2, e->c3, e->headD.a1, e->headD.a2, 2 * B, true, e->dc, nullptr, false));
     // ---- gradient penalty, closed form on the interpolate rows: gpchain.hip, six launches -------------
     GG_TRY(gp_chain(c, D, e->headD.a1 + 2L * B * H, e->headD.a2 + 2L * B * H, B, losses + GG_LOSS_GP, true));
+    phase_mark(c, "critic: MLP head forward / backward + gradient penalty");
     return 0;
 }
 // conditioning backward for the rows that carry gradient (second phase of the critic iteration)
-int critic_cond_phase(Ctx& c, const gg_cond* in) {
+int critic_cond_phase(Ctx& c, const gg_cond* in, int s0 = 0, int s1 = 1 << 20) {
     gg_engine* e = c.e;
     Net& D = e->net[GG_ROLE_CRITIC];
     const int B = in->B, E = e->E;
     const int R = e->crit_R;
     GG_REQUIRE(R == 1 || R == 3, "gg_critic_backward_cond without a preceding gg_critic_backward_head");
-    e->crit_R = 0;
+    if (s1 >= e->nl + 1) e->crit_R = 0;            // the last stage ends the iteration
     if (R == 1) {
-        KL(k_axpy(e->dc, e->dc + (long)B * E, 1.f, (long)B * E, c.st));
-        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 1));
+        if (s0 == 0) KL(k_axpy(e->dc, e->dc + (long)B * E, 1.f, (long)B * E, c.st));
+        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 1, s0, s1));
     } else {
-        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 2));
+        GG_TRY(cond_backward(c, D, in, e->actsD, e->dc, 2, s0, s1));
     }
     return 0;
 }
@@ -1879,18 +1906,20 @@ int generator_head_phase(Ctx& c, const float* z, const gg_cond* in, float* losse
         GG_TRY(generator_forward(c, z, in, e->X2, 1));
         GG_TRY(side_wait(c, 3));
     }
+    phase_mark(c, "generator: G forward beside the frozen critic's conditioning forward");
     GG_TRY(lin_fwd(c, e->X2, G, D.w + D.w1, G + E, nullptr, e->headD.a1, H, B, H, G));
     GG_TRY(head_finish(c, D, e->actsD.c, e->headD.a1, e->headD.a2, e->headD.out, 1, B, B));
     KL(k_gen_loss_seed(e->headD.out, e->dseed, losses, B, c.st));
     // through the frozen critic head down to x_fake, then the generator head and conditioning stack
     GG_TRY(head_backward(c, D, e->dseed, nullptr, nullptr, e->headD.a1, e->headD.a2, B, false, nullptr, e->dxfake));
     GG_TRY(head_backward(c, Gn, e->dxfake, z, e->actsG.c, e->headG.a1, e->headG.a2, B, true, e->dc, nullptr));
+    phase_mark(c, "generator: critic head forward, both heads backward");
     (void)L;
     return 0;
 }
-int generator_cond_phase(Ctx& c, const gg_cond* in) {
+int generator_cond_phase(Ctx& c, const gg_cond* in, int s0 = 0, int s1 = 1 << 20) {
     gg_engine* e = c.e;
-    return cond_backward(c, e->net[GG_ROLE_GENERATOR], in, e->actsG, e->dc, 1);
+    return cond_backward(c, e->net[GG_ROLE_GENERATOR], in, e->actsG, e->dc, 1, s0, s1);
 }
 int generator_backward(Ctx& c, const float* z, const gg_cond* in, float* losses) {
     GG_TRY(generator_head_phase(c, z, in, losses));
@@ -1993,6 +2022,8 @@ void gg_destroy(gg_engine* e) {
         for (int i = 0; i < 5; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
     }
     if (e->side && e->side_own) (void)hipStreamDestroy(e->side);
+    for (hipEvent_t ev : e->phase_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -2145,6 +2176,43 @@ int gg_generator_backward_cond(gg_engine* e, const gg_cond* in, void* stream) {
     Ctx c{e, (hipStream_t)stream};
     return generator_cond_phase(c, in);
 }
+int gg_cond_stage_count(const gg_engine* e) { return !e ? -1 : (e->no_cond ? 0 : e->nl + 2); }
+int gg_cond_stage_range(const gg_engine* e, int role, int stage, int64_t* offset, int64_t* numel) {
+    GG_REQUIRE(e && (role == 0 || role == 1) && offset && numel, "bad argument");
+    GG_REQUIRE(!e->no_cond && stage >= 0 && stage <= e->nl + 1, "gg_cond_stage_range: no such stage");
+    const Net& n = e->net[role];
+    // flat order (build_net): [CLS, FiLM, text encoder, patch encoder][layer 0] .. [layer nl-1][T2I, I2T][MLP head]; ghosts behind `live`
+    const long x0 = e->xattn ? n.t2i.inw : n.w1, l0 = n.layer[0].sa.inw;
+    long a, b;
+    if (stage == 0) { a = x0; b = n.w1; }
+    else if (stage <= e->nl) { const int l = e->nl - stage; a = n.layer[l].sa.inw; b = l + 1 < e->nl ? n.layer[l + 1].sa.inw : x0; }
+    else { a = 0; b = l0; }
+    *offset = a;
+    *numel = b - a;
+    return 0;
+}
+int gg_critic_backward_cond_stage(gg_engine* e, const gg_cond* in, int stage, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    GG_TRY(check_cond(e, in));
+    GG_REQUIRE(stage >= 0 && stage <= e->nl + 1, "gg_critic_backward_cond_stage: no such stage");
+    Ctx c{e, (hipStream_t)stream};
+    return critic_cond_phase(c, in, stage, stage);
+}
+int gg_generator_backward_cond_stage(gg_engine* e, const gg_cond* in, int stage, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    GG_TRY(check_cond(e, in));
+    GG_REQUIRE(stage >= 0 && stage <= e->nl + 1, "gg_generator_backward_cond_stage: no such stage");
+    Ctx c{e, (hipStream_t)stream};
+    return generator_cond_phase(c, in, stage, stage);
+}
+// the engine's side stream (weight-gradient leaves) waits for everything enqueued on `stream` so far: a collective a host then issues
+// from the side stream depends on both streams' share of a stage without the caller's stream waiting for the leaves
+int gg_side_join(gg_engine* e, void* stream) {
+    GG_REQUIRE(e, "null argument");
+    Ctx c{e, (hipStream_t)stream}, cs = c;
+    (void)side_begin(c, cs);
+    return 0;
+}
 int gg_mlp_grad_range(const gg_engine* e, int role, int64_t* offset, int64_t* numel) {
     GG_REQUIRE(e && (role == 0 || role == 1) && offset && numel, "bad argument");
     const Net& n = e->net[role];
@@ -2183,19 +2251,26 @@ int train_step_body(Ctx& c, const float* x_real, const gg_cond* in, const float*
                     float* losses) {
     gg_engine* e = c.e;
     e->launches = 0;
+    e->phase_marks.clear();
+    phase_mark(c, "step begin");
     const long zs = (long)in->B * e->L;
     static const bool defer = getenv("GG_NO_PREFETCH_DEFER") == nullptr;
     if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in, defer));
+    phase_mark(c, "generator: first prefetched pass");
     for (int k = 0; k < n_critic; ++k) {
         if (k == 1) GG_TRY(prefetch_rest(e));           // (no-op unless deferred) output 1 is waited for just below
         GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(c, in->B)));
+        phase_mark(c, "critic: conditioning backward (2 replicas)");
         e->dcond_valid = false;
         GG_TRY(apply_opt(c, e->net[GG_ROLE_CRITIC], e->cfg.clip_d, 1.f));
+        phase_mark(c, "critic: clip + optimiser");
     }
     GG_TRY(prefetch_rest(e));
     e->pre_n = e->pre_next = 0;
     GG_TRY(generator_backward(c, z_all + n_critic * zs, in, losses));
+    phase_mark(c, "generator: conditioning backward");
     GG_TRY(apply_opt(c, e->net[GG_ROLE_GENERATOR], e->cfg.clip_g, 1.f));
+    phase_mark(c, "generator: clip + optimiser");
     return 0;
 }
 
@@ -2442,6 +2517,26 @@ int gg_bind_streams(gg_engine* e, void* side, void* prefetch) {
     return 0;
 }
 
+int gg_phase_enable(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null argument");
+    e->phase_on = on != 0;
+    e->phase_marks.clear();
+    return 0;
+}
+int gg_phase_count(const gg_engine* e) { return e ? (int)e->phase_marks.size() : -1; }
+// mark `index` of the last gg_train_step: its name and the milliseconds since the previous mark (synchronises on the mark's event)
+int gg_phase_read(gg_engine* e, int index, char* name, int name_cap, double* ms) {
+    GG_REQUIRE(e && name && ms && index >= 0 && index < (int)e->phase_marks.size(), "bad argument");
+    snprintf(name, (size_t)name_cap, "%s", e->phase_marks[(size_t)index].first);
+    *ms = 0.0;
+    if (index > 0) {
+        GG_CHECK_HIP(hipEventSynchronize(e->phase_marks[(size_t)index].second));
+        float f = 0.f;
+        GG_CHECK_HIP(hipEventElapsedTime(&f, e->phase_marks[(size_t)index - 1].second, e->phase_marks[(size_t)index].second));
+        *ms = f;
+    }
+    return 0;
+}
 int gg_profile_enable(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     if (on < 0) { e->prof_on = false; return 0; }      // pause: no more event pairs, the records stay for gg_profile_collect

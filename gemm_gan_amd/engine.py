@@ -29,7 +29,7 @@ class Engine:
     def __init__(self, *, n_genes, latent_dims, embedding_dims, hidden_dims, text_dims, patch_dims,
                  n_heads=4, n_layers=2, negative_slope=0.0, dropout=0.1, lr_d=5e-4, lr_g=5e-4,
                  optimizer="rms_prop", gp_weight=10.0, clip_d=10.0, clip_g=2.0, max_batch=8, max_patches=256,
-                 max_text_tokens=1, seed=0, device="cuda:0", precision="f32", variant="xattn_film"):
+                 max_text_tokens=1, seed=0, device="cuda:0", precision="bf16x3", variant="xattn_film"):
         self.lib = L.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -66,6 +66,15 @@ class Engine:
         for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
             L.check(self.lib.gg_mlp_grad_range(self.h, r, C.byref(off), C.byref(numel)))
             self.mlp_range[r] = (off.value, numel.value)
+        # stages of the conditioning backward and the gradient range each completes (reverse flat order: data-parallel hosts all-reduce
+        # a finished stage's range while the next stage runs; include/gemmgan.h gg_cond_stage_range)
+        self.cond_stages = self.lib.gg_cond_stage_count(self.h)
+        self.stage_range = {}
+        for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+            self.stage_range[r] = []
+            for st in range(self.cond_stages):
+                L.check(self.lib.gg_cond_stage_range(self.h, r, st, C.byref(off), C.byref(numel)))
+                self.stage_range[r].append((off.value, numel.value))
 
     # -- construction helpers ------------------------------------------------------------------
     def _read_layout(self, role):
@@ -174,6 +183,16 @@ class Engine:
     def critic_backward_cond(self, patches, patch_pad, text, text_pad):
         cond, keep = self._cond(patches, patch_pad, text, text_pad)
         L.check(self.lib.gg_critic_backward_cond(self.h, C.byref(cond), _stream()))
+
+    def critic_backward_cond_stage(self, stage, patches, patch_pad, text, text_pad):
+        """Stage `stage` (0 .. cond_stages - 1, in order) of the conditioning phase: returns with stage_range[critic][stage] enqueued
+        (its weight-gradient leaves on the side stream)."""
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_critic_backward_cond_stage(self.h, C.byref(cond), int(stage), _stream()))
+
+    def generator_backward_cond_stage(self, stage, patches, patch_pad, text, text_pad):
+        cond, keep = self._cond(patches, patch_pad, text, text_pad)
+        L.check(self.lib.gg_generator_backward_cond_stage(self.h, C.byref(cond), int(stage), _stream()))
 
     def critic_cond_prefetch(self, patches, patch_pad, text, text_pad):
         """The critic's conditioning pass of the next critic iteration on this minibatch, computed ahead."""
@@ -301,6 +320,19 @@ class Engine:
 
     def set_xstore(self, on: bool):
         L.check(self.lib.gg_set_xstore(self.h, int(on)))
+
+    def phase_enable(self, on: bool):
+        """Timing events at the phase boundaries of train_step (include/gemmgan.h gg_phase_*)."""
+        L.check(self.lib.gg_phase_enable(self.h, int(on)))
+
+    def phase_times(self):
+        """[(name, ms since the previous mark)] of the last train_step (synchronises)."""
+        out = []
+        buf, ms = C.create_string_buffer(128), C.c_double()
+        for i in range(self.lib.gg_phase_count(self.h)):
+            L.check(self.lib.gg_phase_read(self.h, i, buf, 128, C.byref(ms)))
+            out.append((buf.value.decode(), ms.value))
+        return out
 
     def set_ffn2(self, mode: int):
         """Streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring)."""

@@ -175,7 +175,7 @@ class WGAN_GP:
                  n_critic=5, freq_print=2, freq_compute_test=50, freq_visualize_test=100, patience=10,
                  normalization="standardize", log2=False, rpm=False, results_dire="",
                  # --- extensions (keyword-only in spirit; defaults reproduce the reference) ---
-                 dropout=0.1, seed=0, device=None, process_group=None, precision="f32"):
+                 dropout=0.1, seed=0, device=None, process_group=None, precision="bf16x3"):
         self.input_dims = input_dims
         self.latent_dims = latent_dims
         self.embedding_dims = embedding_dims
@@ -214,7 +214,10 @@ class WGAN_GP:
         self.dropout = dropout
         self.seed = seed
         self.process_group = process_group
-        self.precision = precision          # "f32": exact-fp32 MFMA (parity mode); "bf16": bf16 MFMA, fp32 accumulate
+        # "bf16x3" (default): the fused kernels on fp32 operands split into bf16 parts - the reference's <= 1e-3 tolerance at 2.5x the speed of
+        # "f32" (exact fp32-input MFMA on the generic kernels; shapes the split-operand kernels do not take fall back to it per call);
+        # "bf16": bf16 MFMA operands, fp32 accumulate (the throughput mode of bench.py); "fp8": bf16 with e4m3 forward Linears
+        self.precision = precision
         self.engine: Optional[Engine] = None
         self.gen = self.disc = None
         self.optimizer_disc = self.optimizer_gen = None
@@ -322,6 +325,24 @@ class WGAN_GP:
         t = g[off:off + numel] if which == "mlp" else g[:off]
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
 
+    def _allreduce_stage(self, role, stage):
+        """Asynchronous SUM all-reduce of the gradient range conditioning-backward stage `stage` has just enqueued.  The range's
+        weight gradients are leaves on the engine's side stream: the collective is issued FROM that stream after it has joined the
+        caller's (it then depends on both streams' share of the stage), so the caller's stream goes on with the next stage at once."""
+        import torch.distributed as dist
+        if self._world() == 1:
+            return None
+        off, numel = self.engine.stage_range[role][stage]
+        if numel == 0:
+            return None
+        t = self.engine.flat[role]["g"][off:off + numel]
+        side = getattr(self.engine, "_side_stream", None)
+        if side is not None and t.is_cuda:
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+
     def _wait(self, *works):
         """The compute stream waits for the collectives; with `measure_comm` the exposed wait is timed with an event pair."""
         timed = self.measure_comm and self.device.type == "cuda"
@@ -401,22 +422,36 @@ class WGAN_GP:
         travel while the conditioning stack's backward runs (SURVEY 8e "Overlap")."""
         eng = self.engine
         eng.critic_backward_head(x, z, alpha, pat, ppad, text, tpad)
-        h1 = self._allreduce_bucket(L.ROLE_CRITIC, "mlp")
-        eng.critic_backward_cond(pat, ppad, text, tpad)
-        h2 = self._allreduce_bucket(L.ROLE_CRITIC, "cond")
-        self._wait(h1, h2)
+        hs = [self._allreduce_bucket(L.ROLE_CRITIC, "mlp")]
+        n_st = getattr(eng, "cond_stages", 0)
+        if n_st > 0 and not os.environ.get("GG_DP_TWO_BUCKETS"):
+            # reverse-layer buckets (round 4): cross-attention, encoder layers last to first, then CLS / patch encoder / FiLM / text
+            # encoder - contiguous ranges of the flat buffer in backward order; only the last one is exposed
+            for st in range(n_st):
+                eng.critic_backward_cond_stage(st, pat, ppad, text, tpad)
+                hs.append(self._allreduce_stage(L.ROLE_CRITIC, st))
+        else:
+            eng.critic_backward_cond(pat, ppad, text, tpad)
+            hs.append(self._allreduce_bucket(L.ROLE_CRITIC, "cond"))
+        self._wait(*hs)
 
     def _generator_iteration_dp(self, z, pat, ppad, text, tpad, next_cond=None):
         """Same for the generator; `next_cond` = (patches, pad, text, text_pad) of the NEXT train(): the critic's conditioning
         forward of its first critic iteration does not depend on the generator and runs under the all-reduce."""
         eng = self.engine
         eng.generator_backward_head(z, pat, ppad, text, tpad)
-        h1 = self._allreduce_bucket(L.ROLE_GENERATOR, "mlp")
-        eng.generator_backward_cond(pat, ppad, text, tpad)
-        h2 = self._allreduce_bucket(L.ROLE_GENERATOR, "cond")
+        hs = [self._allreduce_bucket(L.ROLE_GENERATOR, "mlp")]
+        n_st = getattr(eng, "cond_stages", 0)
+        if n_st > 0 and not os.environ.get("GG_DP_TWO_BUCKETS"):
+            for st in range(n_st):
+                eng.generator_backward_cond_stage(st, pat, ppad, text, tpad)
+                hs.append(self._allreduce_stage(L.ROLE_GENERATOR, st))
+        else:
+            eng.generator_backward_cond(pat, ppad, text, tpad)
+            hs.append(self._allreduce_bucket(L.ROLE_GENERATOR, "cond"))
         if next_cond is not None:
             eng.critic_cond_prefetch(*next_cond)
-        self._wait(h1, h2)
+        self._wait(*hs)
 
     # ---- losses (R:421-423, R:458-460) -------------------------------------------------------------------------------
     # The reference publishes disc_loss / gen_loss (0-d tensors) and d_batch_loss / g_batch_loss (numpy) after every call,

@@ -108,7 +108,7 @@ class WGAN_GP_nocond(_m.WGAN_GP):
                  is_bn=False, numerical_dims=(), lr_d=5e-4, lr_g=5e-4, optimizer="rms_prop", gp_weight=10, p_aug=0,
                  norm_scale=0.5, train=True, n_critic=5, freq_print=2, freq_compute_test=10, freq_visualize_test=100,
                  patience=10, normalization="standardize", log2=False, rpm=False, results_dire="",
-                 seed=0, device=None, process_group=None, precision="f32"):
+                 seed=0, device=None, process_group=None, precision="bf16x3"):
         super().__init__(input_dims, latent_dims, _E, generator_dims, discriminator_dims, text_embedding_dims=8,
                          patches_embedding_dims=8, negative_slope=negative_slope, is_bn=is_bn, lr_d=lr_d, lr_g=lr_g,
                          optimizer=optimizer, gp_weight=gp_weight, p_aug=p_aug, norm_scale=norm_scale, train=train,

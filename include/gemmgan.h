@@ -145,6 +145,18 @@ int gg_critic_backward_cond(gg_engine* e, const gg_cond* c, void* stream);
 /* [offset, offset + numel) of the flat gradient buffer: the MLP-head parameters (`<mlp>.0.0`, `<mlp>.1.0`, final_layer),
  * the last entries of the state_dict order; [0, offset) are the conditioning-stack parameters */
 int gg_mlp_grad_range(const gg_engine* e, int role, int64_t* offset, int64_t* numel);
+/* The conditioning phase in stages, so that a data-parallel host can all-reduce the gradient range of a finished stage while the next one
+ * runs (only the last range is exposed): stage 0 = the cross-attention blocks, 1 .. n_layers = encoder layers from the last to the first,
+ * n_layers + 1 = replica fold, CLS token, patch encoder, FiLM, text encoder.  gg_cond_stage_count() = n_layers + 2 (0: unconditional model);
+ * gg_cond_stage_range() = the contiguous slice of the flat gradient buffer stage `stage` completes (backward order = reverse flat order).
+ * The stages of one iteration are called in order 0 .. count-1 after gg_*_backward_head; gg_*_backward_cond runs them all.  A stage's
+ * weight-gradient leaves run on the engine's side stream: gg_side_join() makes that stream wait for the caller's, so a collective
+ * issued from the side stream sees the whole stage (R:412 loss.backward(); SURVEY 8e "Overlap"). */
+int gg_cond_stage_count(const gg_engine* e);
+int gg_cond_stage_range(const gg_engine* e, int role, int stage, int64_t* offset, int64_t* numel);
+int gg_critic_backward_cond_stage(gg_engine* e, const gg_cond* c, int stage, void* stream);
+int gg_generator_backward_cond_stage(gg_engine* e, const gg_cond* c, int stage, void* stream);
+int gg_side_join(gg_engine* e, void* stream);
 /* The critic's conditioning pass (R:403,404,360: its three dropout draws) of the NEXT gg_critic_backward[_head] call on the
  * same minibatch shape, computed ahead: it depends on the critic's weights and the conditioning inputs only, so a
  * data-parallel host runs it under the generator's gradient all-reduce.  Discarded by anything that changes the critic's
@@ -311,6 +323,12 @@ int gg_debug_buffer_is_bf16(gg_engine* e, const char* name);   /* 1 if that buff
  * gg_profile_collect synchronises the events and aggregates per kernel class (= kernel symbol:
  * "gemm_f32<A-layout,B-layout>") launches, total milliseconds, algorithmic FLOPs (2*M*N*K*batch) and
  * algorithmic bytes ((M*K + K*N + M*N)*4*batch).  gg_profile_read returns row i of the aggregate. */
+/* phase marks: timing events recorded on the caller's stream at the phase boundaries of gg_train_step (conditioning forward, MLP head +
+ * gradient penalty, conditioning backward, optimiser; per critic iteration and for the generator iteration) - the timeline of an
+ * UN-profiled step (a tracer slows the host's enqueue enough to open gaps that do not exist otherwise).  bench.py: roofline.step.phases */
+int gg_phase_enable(gg_engine* e, int on);
+int gg_phase_count(const gg_engine* e);
+int gg_phase_read(gg_engine* e, int index, char* name, int name_cap, double* ms);
 int gg_profile_enable(gg_engine* e, int on);
 int gg_profile_enable_class(gg_engine* e, const char* name);   /* event pairs for ONE class, by its gg_profile_read name */
 int gg_profile_collect(gg_engine* e);            /* returns number of classes, <0 on error */

@@ -38,6 +38,26 @@ class OracleEngine:
         for r, n in self.nets.items():
             sizes = [p.numel() for _, p in live_parameters(n)]
             self.mlp_range[r] = (sum(sizes[:-6]), sum(sizes[-6:]))
+        # stages of the conditioning backward and the contiguous gradient range each completes (include/gemmgan.h gg_cond_stage_range):
+        # 0 cross-attention, 1 .. nl encoder layers last to first, nl + 1 CLS / FiLM / text encoder / patch encoder
+        nl = trainer.cfg.n_layers
+        self.cond_stages = nl + 2
+        self.stage_range = {}
+        for r, n in self.nets.items():
+            names = [(nm, p.numel()) for nm, p in live_parameters(n)]
+            offs = np.cumsum([0] + [k for _, k in names])
+
+            def rng(pred):
+                idx = [i for i, (nm, _) in enumerate(names) if pred(nm)]
+                assert idx == list(range(idx[0], idx[-1] + 1)), "a stage's parameters must be contiguous in the flat buffer"
+                return int(offs[idx[0]]), int(offs[idx[-1] + 1] - offs[idx[0]])
+            st = [rng(lambda nm: nm.startswith(("patch2text_attention.", "text2patch_attention.")))]
+            st += [rng(lambda nm, l=l: nm.startswith(f"patches_transformer.layers.{l}.")) for l in range(nl - 1, -1, -1)]
+            st.append(rng(lambda nm: nm.startswith(("patches_cls_token", "film_generator.", "text_encoder.", "patches_encoder."))))
+            self.stage_range[r] = st
+            covered = sorted(st + [self.mlp_range[r]])
+            assert covered[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:])) and \
+                covered[-1][0] + covered[-1][1] == offs[-1], "stage ranges + MLP range must tile the flat gradient buffer"
         self.calls = []
 
     def set_lr(self, role, lr):
@@ -70,6 +90,12 @@ class OracleEngine:
 
     def critic_backward_cond(self, pat, ppad, text, tpad):
         self.calls.append(("critic_cond",))
+
+    def critic_backward_cond_stage(self, stage, pat, ppad, text, tpad):
+        self.calls.append((f"critic_cond{stage}",))
+
+    def generator_backward_cond_stage(self, stage, pat, ppad, text, tpad):
+        self.calls.append((f"gen_cond{stage}",))
 
     def critic_cond_prefetch(self, pat, ppad, text, tpad):
         self.calls.append(("critic_cond_prefetch", pat.clone()))
@@ -140,7 +166,9 @@ def _worker(rank, world, port, q):
         w.train_with_noise(x[s], text[s], text_pad[s], patches[s], patch_pad[s], z_all[:, s].contiguous(),
                            alpha_all[:, s].contiguous(), next_cond=(patches[s], patch_pad[s], text[s], text_pad[s]))
         order = [c[0] for c in w.engine.calls]
-        assert order == ["critic_head", "critic_cond"] * CFG.n_critic + ["gen_head", "gen_cond", "critic_cond_prefetch"], order
+        stages = [str(i) for i in range(CFG.n_layers + 2)]
+        assert order == (["critic_head"] + ["critic_cond" + i for i in stages]) * CFG.n_critic + ["gen_head"] + \
+            ["gen_cond" + i for i in stages] + ["critic_cond_prefetch"], order
         sd = {k: v.detach().numpy().copy() for k, v in {**{"g." + k: v for k, v in tr.gen.state_dict().items()},
                                                          **{"d." + k: v for k, v in tr.disc.state_dict().items()}}.items()}
         d_loss_global = float(w.d_batch_loss[0])

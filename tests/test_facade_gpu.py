@@ -36,11 +36,24 @@ class Replay:
         torch.rand, torch.normal = self._r, self._n
 
 
+PREC = None
+
+
+@pytest.fixture(params=[None, "f32"], ids=["default-precision", "f32"], autouse=True)
+def facade_precision(request):
+    """Every facade test runs twice: with the drop-in default (`precision` not given: bf16x3 since round 4) and in the exact f32 mode."""
+    global PREC
+    PREC = request.param
+    yield
+    PREC = None
+
+
 def build(g: Golden, optimizer="rms_prop"):
     d = g.dims
     w = gga.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
                     patches_embedding_dims=d["Dp"], negative_slope=g.slope, optimizer=optimizer, n_critic=d["n_critic"],
-                    dropout=0.0, device="cuda:0")
+                    dropout=0.0, device="cuda:0", **({} if PREC is None else {"precision": PREC}))
+    assert w.precision == (PREC or "bf16x3")
     w.build_WGAN_GP()
     w.init_train()
     w.gen.load_state_dict(g.state("init_gen"))

@@ -13,12 +13,24 @@ pytestmark = pytest.mark.gpu
 FILM_FIXTURES = ["film_P1", "film_P7", "img_P9"]      # the 4-argument sibling files: FiLM-only and image-transformer
 
 
+PREC = None
+
+
+@pytest.fixture(params=[None, "f32"], ids=["default-precision", "f32"], autouse=True)
+def facade_precision(request):
+    """Every facade test runs twice: with the drop-in default (`precision` not given: bf16x3 since round 4) and in the exact f32 mode."""
+    global PREC
+    PREC = request.param
+    yield
+    PREC = None
+
+
 def build(g: Golden, opt="rms_prop", **kw):
     d = g.dims
     mod = img_transformer if g.variant == "img" else film
     w = mod.WGAN_GP(d["G"], d["L"], d["E"], [d["H"], d["H"], d["G"]], [d["H"], d["H"], 1], text_embedding_dims=d["Dt"],
                     patches_embedding_dims=d["Dp"], negative_slope=g.slope, optimizer=opt, n_critic=d["n_critic"],
-                    dropout=0.0, device="cuda:0", **kw)
+                    dropout=0.0, device="cuda:0", **({} if PREC is None else {"precision": PREC}), **kw)
     w.build_WGAN_GP()
     w.init_train()
     return w
