@@ -99,6 +99,7 @@ SYMBOLS = {
     "gg_set_tlin": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_ffn_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_ffn2": (C.c_int, [C.c_void_p, C.c_int]),
+    "gg_set_encb": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_xstore": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_lnb_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_head_fused": (C.c_int, [C.c_void_p, C.c_int]),
@@ -109,6 +110,8 @@ SYMBOLS = {
     "gg_test_ffn2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_void_p, C.c_int, C.c_void_p]),
+    "gg_test_enc_bwd_frag_bytes": (C.c_int64, []),
+    "gg_test_enc_bwd": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gg_set_sqx": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_bstore": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_set_wgrad": (C.c_int, [C.c_void_p, C.c_int]),

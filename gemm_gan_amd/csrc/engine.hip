@@ -49,6 +49,7 @@ struct Net {
     char *wb = nullptr, *wtb = nullptr;
     char *wp3 = nullptr, *wtp3 = nullptr;     // bf16x3 mode: three bf16 parts (hi, mid, lo) of W / W^T, part sp at + 2 * total * sp bytes
     // fp8 mode: e4m3 shadow of the same weights (tensor at byte offset 2 * flat offset), per-tensor exponents
+    char* wfragb = nullptr;                   // ... and of linear2^T / linear1^T / out_proj^T for the fused backward kernel
     char* wfrag = nullptr;                    // fragment-ordered bf16 image of linear1 / linear2 of every encoder layer (enc.hip: the fused feed-forward stream)
     char* w8 = nullptr;
     unsigned* w8_amax = nullptr;
@@ -189,6 +190,7 @@ struct gg_engine {
     int sqx_on = 1;            // single-query T2I attention without K/V projections (any precision)
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
+    int encb_on = getenv("GG_ENCB") ? atoi(getenv("GG_ENCB")) : 0;     // fused backward of the token-local chain behind LayerNorm2's backward (enc.hip encb_kernel)
     int ffn2_on = getenv("GG_FFN2") ? atoi(getenv("GG_FFN2")) : 0;     // 1 + variant: the streamed fused feed-forward block (enc.hip) in bf16 mode with bf16-stored LayerNorm outputs
     int ffn_on = getenv("GG_FFN_FUSED") != nullptr;   // fused feed-forward block (ffn.hip), bf16 mode, E = 256: opt-in (or gg_set_ffn_fused) -
                                // measured 20 % slower than the two launches it replaces (profiles/r03_ffn_fused.md)
@@ -420,6 +422,7 @@ size_t carve(gg_engine* e, void* base) {
         n.w8_amax = a.take<unsigned>(n.tab.size() + 1);
         n.w8_exp = a.take<int>(n.tab.size() + 1);
         n.wfrag = a.take<char>(enc_frag_bytes(e->nl));
+        n.wfragb = a.take<char>(encb_frag_bytes(e->nl));
     }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
@@ -668,6 +671,11 @@ int refresh_shadows(Ctx& c, Net& n) {
         long o1[MAXL], o2[MAXL];
         for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; }
         KL(k_enc_frag_weights(n.w, o1, o2, c.e->nl, n.wfrag, c.st));
+    }
+    if (c.e->encb_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {
+        long o1[MAXL], o2[MAXL], oo[MAXL];
+        for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; oo[l] = n.layer[l].sa.ow; }
+        KL(k_encb_frag_weights(n.w, o1, o2, oo, c.e->nl, n.wfragb, c.st));
     }
     if (c.e->fp8_fwd) {
         GG_TRY(k_shadow_weights_fp8(n.w, n.w8, n.w8_amax, n.w8_exp, n.tab_dev, (int)n.tab.size(), c.st));
@@ -1326,6 +1334,35 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             GG_TRY(lin_bwd_weight(cs, e->sdres, E, L.h, F, g + lp.l2w, F, (int)(RB * S), E, F, bst, bst));
             GG_TRY(side_end(c, fk, 0));
         }
+        bool fusedb = false;
+        if (bst && a.xst && a.rst && e->encb_on && e->lnb_on && E == 256 && F == 512 && !e->x3) {
+            // MASK -> dx1 += -> LayerNorm1 backward -> dctx in one streamed launch (enc.hip): dr2 in sdr, dres2 in sdres; dr1 -> dx, dh -> sdh,
+            // dres1 -> the second bf16 image of sdres, dctx -> sdctx
+            EncBwdP q;
+            q.dx = dx; q.dr2 = e->sdr; q.M = RB * S; q.Wf = n.wfragb + (size_t)l * encb_frag_bytes(1);
+            q.dres2 = e->sdres; q.h = L.h; q.r1 = L.r1; q.st1 = L.st1; q.g1 = w + lp.n1w;
+            q.dh = e->sdh; q.dres1 = reinterpret_cast<__bf16*>(e->sdres) + RB * S * E; q.dctx = e->sdctx;
+            q.dg1 = g + lp.n1w; q.db1 = g + lp.n1b; q.dbias1 = g + lp.sa.ob;
+            q.drop1 = dkey(e, a, n.role, l, 1); q.gate_scale = ks;
+            if (enc_bwd_supported(q)) {
+                GG_TRY(side_wait(c, 1));
+                GG_TRY(side_wait(c, 4));
+                {
+                    const double tokd = (double)RB * S;
+                    ProfScope ps(c, "encb_kernel", 2.0 * tokd * (2.0 * E * F + (double)E * E), tokd * (4.0 * E * 2 + 2.0 * E * 4 + 2.0 * F * 2) + 2.0 * (2.0 * E * F + E * E));
+                    KL(enc_bwd(q, c.st));
+                }
+                fusedb = true;
+                Ctx cs = c;
+                const bool fk = side_begin(c, cs);
+                GG_TRY(lin_bwd_weight(cs, e->sdh, F, L.x1, E, g + lp.l1w, E, (int)(RB * S), F, E, bst, a.xst, nullptr, g + lp.l1b));
+                GG_TRY(side_end(c, fk, 1));
+                const bool fk2 = side_begin(c, cs);
+                GG_TRY(lin_bwd_weight(cs, reinterpret_cast<const float*>(q.dres1), E, L.ctx, E, g + lp.sa.ow, E, (int)(RB * S), E, E, bst, bst));
+                GG_TRY(side_end(c, fk2, 4));
+            }
+        }
+        if (!fusedb) {
         GG_TRY(side_wait(c, 1));
         {   // dhpre = (df W2) * [h > 0] / (1-p) : the stored post-dropout h gates both ReLU and the kept-mask
             TlinP t;
@@ -1391,6 +1428,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             if (bst) TLIN_MUST(t);
             else TLIN_OR(t, GG_TRY(lin_bwd_data(c, dres1, E, w + lp.sa.ow, E, e->sdctx, E, (int)(RB * S), E, E)));
         }
+        }   // !fusedb
         const DropKey kA = dkey(e, a, n.role, l, 0);
         GG_TRY(side_wait(c, 2));
         if (a.flash) {
@@ -2284,7 +2322,7 @@ void step_signature(const gg_engine* e, const float* x_real, const gg_cond* in, 
         (uint64_t)(uintptr_t)in->text_pad, (uint64_t)in->B, (uint64_t)in->P, (uint64_t)in->T, (uint64_t)n_critic,
         (uint64_t)e->precision | (uint64_t)e->fp8_fwd << 8 | (uint64_t)e->side_on << 9 | (uint64_t)e->prefetch_on << 10 |
             (uint64_t)e->flash << 11 | (uint64_t)e->tlin_on << 12 | (uint64_t)e->wgrad_on << 13 | (uint64_t)e->bstore_on << 14 |
-            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21 | (uint64_t)e->head_on << 22 | (uint64_t)e->ffn2_on << 23,
+            (uint64_t)e->small_on << 15 | (uint64_t)e->sqx_on << 16 | (uint64_t)e->x3 << 17 | (uint64_t)e->ffn_on << 18 | (uint64_t)e->xstore_on << 19 | (uint64_t)e->lnb_on << 20 | (uint64_t)e->rstore_on << 21 | (uint64_t)e->head_on << 22 | (uint64_t)e->ffn2_on << 23 | (uint64_t)e->encb_on << 26,
         bits(e->dropout), bits(e->net[0].lr), bits(e->net[1].lr), (uint64_t)e->seed, (uint64_t)(uintptr_t)e->ws};
     for (int r = 0; r < 2; ++r)
         for (const float* q : {e->net[r].w, e->net[r].g, e->net[r].s1, e->net[r].s2}) v.push_back((uint64_t)(uintptr_t)q);
@@ -2423,6 +2461,12 @@ int gg_set_prefetch(gg_engine* e, int on) {
 int gg_set_flash(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
     e->flash = on != 0;
+    return 0;
+}
+int gg_set_encb(gg_engine* e, int on) {
+    GG_REQUIRE(e, "null engine");
+    e->encb_on = on != 0;
+    drop_graphs(e);
     return 0;
 }
 int gg_set_ffn2(gg_engine* e, int mode) {

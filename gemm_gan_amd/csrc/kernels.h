@@ -191,6 +191,27 @@ size_t enc_frag_bytes(int nl);                      // bytes of the fragment-ord
 // out[layer] = fragment stream of linear1.weight [512][256] at w + w1_off[layer] and linear2.weight [256][512] at w + w2_off[layer]
 int k_enc_frag_weights(const float* w, const long* w1_off, const long* w2_off, int nl, void* out, hipStream_t st);
 
+// fused backward of the token-local chain of an encoder layer behind LayerNorm2's backward (enc.hip): gated hidden gradient -> dx1 += -> LayerNorm1
+// backward -> context gradient in one launch; bf16 tensors as in the default bf16 mode
+struct EncBwdP {
+    float* dx = nullptr; long M = 0;                // out: dr1 [M,256] fp32 (gradient w.r.t. the pre-LN1 sum)
+    const float* dr2 = nullptr;                     // in: gradient w.r.t. the pre-LN2 sum, fp32 [M,256] (null: in dx, overwritten in place)
+    const void* Wf = nullptr;                       // this layer's backward fragment stream (encb_frag_bytes(1) bytes)
+    const void* dres2 = nullptr;                    // bf16 [M,256] masked branch gradient of LayerNorm2 (ln_bwd_v4_k)
+    const void* h = nullptr;                        // bf16 [M,512] stored hidden activations (post ReLU and dropout)
+    const void* r1 = nullptr; const float* st1 = nullptr; const float* g1 = nullptr;     // bf16 pre-LN1 sums, (mean, rstd) [M,2], norm1.weight
+    void* dh = nullptr; void* dres1 = nullptr; void* dctx = nullptr;          // bf16 [M,512], [M,256], [M,256]
+    float* dg1 = nullptr; float* db1 = nullptr; float* dbias1 = nullptr;      // += norm1.weight / norm1.bias / out_proj.bias gradients [256]
+    DropKey drop1;                                  // post-attention dropout (site 1), element index = token * 256 + n
+    float gate_scale = 1.f;                         // 1 / (1 - p) of the inner (FFN) dropout: dh = (dres2 W2) * [h > 0] * gate_scale
+    unsigned* stamps = nullptr;                     // tools/encb_probe.py: per-phase cycle sums, [workgroups * 8][8]
+};
+bool enc_bwd_supported(const EncBwdP& p);
+int enc_bwd(const EncBwdP& p, hipStream_t st);
+size_t encb_frag_bytes(int nl);
+// out[layer] = backward fragment stream of linear2.weight [256][512] (as W2^T), linear1.weight [512][256] (as W1^T) and out_proj.weight [256][256] (as Wo^T)
+int k_encb_frag_weights(const float* w, const long* w1_off, const long* w2_off, const long* wo_off, int nl, void* out, hipStream_t st);
+
 // split-operand (bf16x3) attention of GG_PREC_BF16X3: fp32 qkv / ctx / dctx / dqkv, `ns` bf16 parts per MFMA operand (2: three
 // products per tile - the backward form; 3: six products, fp32-grade - the forward form); any S <= 2048 (keys / queries streamed)
 bool flash_attn_x3_supported(int S, int E, int nh);

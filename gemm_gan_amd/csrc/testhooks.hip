@@ -113,6 +113,27 @@ int gg_test_ffn2(const void* X, int64_t M, const float* W1, const float* b1, con
     return ffn2(f, (hipStream_t)stream, variant);
 }
 
+// fused backward of the token-local chain of an encoder layer behind LayerNorm2's backward (enc.hip encb_kernel): Wcat = linear1.weight [512,256] |
+// linear2.weight [256,512] | out_proj.weight [256,256] (fp32, contiguous); the backward fragment stream is built into wfrag
+// (gg_test_enc_bwd_frag_bytes() bytes); colsums [3][256] += dgamma1, dbeta1, dbias1 (out_proj.bias)
+int64_t gg_test_enc_bwd_frag_bytes(void) { return (int64_t)encb_frag_bytes(1); }
+int gg_test_enc_bwd(float* dx, int64_t M, const float* Wcat, const void* dres2, const void* h, const void* r1, const float* st1, const float* g1,
+                    void* dh, void* dres1, void* dctx, float* colsums, float drop_p, uint64_t drop_seed, uint32_t site1, uint32_t drop_call,
+                    void* wfrag, void* stream) {
+    GG_REQUIRE(dx && Wcat && wfrag && colsums, "null argument");
+    const long o1 = 0, o2 = 512L * 256, oo = 2L * 512 * 256;
+    GG_TRY(k_encb_frag_weights(Wcat, &o1, &o2, &oo, 1, wfrag, (hipStream_t)stream));
+    EncBwdP p;
+    p.dx = dx; p.M = M; p.Wf = wfrag; p.dres2 = dres2; p.h = h; p.r1 = r1; p.st1 = st1; p.g1 = g1;
+    p.dh = dh; p.dres1 = dres1; p.dctx = dctx;
+    p.dg1 = colsums; p.db1 = colsums + 256; p.dbias1 = colsums + 512;
+    p.drop1 = make_drop_key(drop_p, drop_seed, site1, drop_call & 0x3fffffffu);
+    p.gate_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    if (drop_call >= 0x40000000u) p.stamps = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(wfrag) + encb_frag_bytes(1));     // probe: + 256 * 8 * 8 words behind the image
+    GG_REQUIRE(enc_bwd_supported(p), "gg_test_enc_bwd: unsupported operands");
+    return enc_bwd(p, (hipStream_t)stream);
+}
+
 int gg_test_head_fwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* b1, const float* W2,
                      const float* b2, const float* w3, const float* b3, const float* cvec, float* a1, float* a2, float* out,
                      int64_t out_rows, void* stream) {

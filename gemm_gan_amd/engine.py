@@ -334,6 +334,10 @@ class Engine:
             out.append((buf.value.decode(), ms.value))
         return out
 
+    def set_encb(self, on: bool):
+        """Fused backward of the token-local chain of an encoder layer (csrc/enc.hip encb_kernel)."""
+        L.check(self.lib.gg_set_encb(self.h, int(on)))
+
     def set_ffn2(self, mode: int):
         """Streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring)."""
         L.check(self.lib.gg_set_ffn2(self.h, int(mode)))

@@ -221,6 +221,7 @@ int gg_set_xstore(gg_engine* e, int on);              /* bf16 storage of the enc
                                                           for the backward pass, bf16 mode at E = 256 (default 1; 0 off; 3 = outputs only) */
 int gg_set_sqx(gg_engine* e, int on);                 /* projection-free single-query T2I attention (default on) */
 int gg_set_tlin(gg_engine* e, int on);                /* token-on-lane Linear kernels in bf16 mode (default on) */
+int gg_set_encb(gg_engine* e, int on);                 /* fused backward of an encoder layer's token-local chain behind LayerNorm2's backward (csrc/enc.hip): one launch for the gated hidden gradient, dx1 +=, LayerNorm1 backward and the context gradient */
 int gg_set_ffn2(gg_engine* e, int mode);               /* streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring); needs the bf16-stored LayerNorm outputs */
 int gg_set_ffn_fused(gg_engine* e, int on);           /* fused feed-forward block (one launch per layer) in bf16 mode at E = 256 (default off: measured slower than the two launches) */
 int gg_reset_optimizer_steps(gg_engine* e);           /* after (re)binding zeroed optimiser state */
@@ -301,6 +302,15 @@ int gg_test_sqx_bwd(const float* dxbar, const float* qt, const float* xbar, cons
  * act(a1 + cvec W1c^T + b1) on return, a2 = act(a1 W2^T + b2), out[r] = a2[r] . w3 + b3 for r < out_rows (out may be null).
  * backward: dout [rows] (score gradient; null: dh2 holds dout W3 on entry) -> dh2, dh1 [rows,H], dcond [rows,E] (may be null).
  * W1c: [H][E] slice of the first-layer weight, row stride ldw1.  LeakyReLU(slope). */
+/* fused backward of an encoder layer's token-local chain behind LayerNorm2's backward (csrc/enc.hip encb_kernel; torch transformer.py:961-983
+ * differentiated): dx [M,256] fp32 in (dr2, the gradient w.r.t. the pre-LN2 sum) and out (dr1, w.r.t. the pre-LN1 sum); dres2 bf16 [M,256] the masked
+ * branch gradient of LayerNorm2; Wcat = linear1.weight | linear2.weight | out_proj.weight (fp32, contiguous); r1 bf16 pre-LN1 sums, st1 (mean, rstd)
+ * [M,2], g1 norm1.weight, h bf16 [M,512] stored hidden activations; outputs bf16: dh [M,512], dres1 [M,256], dctx [M,256]; colsums [3][256] +=
+ * dgamma1, dbeta1, d(out_proj.bias) */
+int64_t gg_test_enc_bwd_frag_bytes(void);
+int gg_test_enc_bwd(float* dx, int64_t M, const float* Wcat, const void* dres2, const void* h, const void* r1, const float* st1, const float* g1,
+                    void* dh, void* dres1, void* dctx, float* colsums, float drop_p, uint64_t drop_seed, uint32_t site1, uint32_t drop_call,
+                    void* wfrag, void* stream);
 int gg_test_head_fwd(int64_t rows, int H, int E, float slope, const float* W1c, int64_t ldw1, const float* b1, const float* W2,
                      const float* b2, const float* w3, const float* b3, const float* cvec, float* a1, float* a2, float* out,
                      int64_t out_rows, void* stream);

@@ -607,6 +607,51 @@ def test_fused_feed_forward_route_matches_the_two_launch_route(dropout):
     ck.done()
 
 
+@pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fused_layer_backward_route_matches_the_three_launch_route(dropout, case):
+    """enc.hip encb_kernel (gg_set_encb) inside a critic and a generator iteration against the gate, += / LayerNorm-backward and context-gradient
+    Linears as three weight-stationary launches: same operands and dropout streams, same bf16 storage; fp32 summation order and the bf16
+    rounding of values on a tie differ."""
+    c = CASES[case]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    batch = synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True)
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_dropout(dropout)
+    eng.set_precision("bf16")
+    x, text, text_pad, patches, patch_pad = dev(*batch)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, cfg.latent_dims, generator=g).cuda()
+    alpha = torch.rand(B, generator=g).cuda()
+    out = {}
+    for on in (False, True):
+        eng.set_encb(on)
+        eng.set_seed(5)
+        eng.reset_launch_count()
+        eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
+        out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(), launches=eng.launch_count(),
+                       gs={k: v.clone() for k, v in eng.state(L.ROLE_CRITIC, "g").items()})
+        eng.generator_backward(z, patches, patch_pad, text, text_pad)
+        out[on]["gg"] = eng.flat[L.ROLE_GENERATOR]["g"].clone()
+    eng.set_encb(False)
+    a, b = out[True], out[False]
+    assert a["launches"] < b["launches"], (a["launches"], b["launches"])           # two launches less per layer, one more per shadow refresh
+    ck = Checker(f"fused layer backward vs three launches, {case}, dropout={dropout}", 5e-3, metric="max")
+    ck.check("critic losses", a["losses"][:3], b["losses"][:3], tol=1e-6)        # the forward pass is the same code
+    from test_bf16_parity_gpu import significant
+    for k in a["gs"]:
+        if significant(b["gs"][k]):
+            ck.check("dD " + k, a["gs"][k], b["gs"][k])
+    cd, cg = _cos(a["g"], b["g"]), _cos(a["gg"], b["gg"])
+    from gpu_util import diag
+    diag(f"   flat gradient cosine fused vs three launches: critic {cd:.6f}, generator {cg:.6f}")
+    assert cd > 0.9999 and cg > 0.9999, (cd, cg)
+    ck.done()
+
+
 @pytest.mark.parametrize("mode", [1, 3])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_streamed_feed_forward_route_matches_the_two_launch_route(dropout, mode):

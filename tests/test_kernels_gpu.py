@@ -902,3 +902,76 @@ def test_fused_feed_forward_stream_kernel_equals_the_fp64_result(M, keep_rows, d
         diag(f"   {k:44s} rel-L2 {v[0]:.2e}  max-norm {v[1]:.2e}")
     if kr < M:
         assert torch.isnan(h_d[kr:].float()).all() and torch.isnan(r2_d[kr:].float()).all() and torch.isnan(st_d[kr:]).all()
+
+
+# ---- fused backward of the token-local chain of an encoder layer (csrc/enc.hip encb_kernel) -------------------------------------------
+@pytest.mark.parametrize("M,drop_on", [(8 * 257, True), (5 * 257 + 3, False), (33, True), (70000, True), (512 * 257, True)])
+def test_fused_encoder_layer_backward_equals_the_fp64_result(M, drop_on):
+    """encb_kernel: dh = (dres2 W2) gated by the stored hidden activations -> dx1 = dr2 + dh W1 -> LayerNorm1 backward (dr1 over dr2 in place,
+    masked bf16 branch gradient dres1, three per-feature sums) -> dctx = dres1 Wo.  Inputs dr2 / dres2 are what ln_bwd_v4_k (LayerNorm2
+    backward) leaves.  Reference in float64 on the values the MFMAs see (dres2 / dh / dres1 as bf16); dropout mask regenerated on the host.
+    M = 70 000 and 512 * 257 (the cfg3 backward shape): several sweeps per workgroup and a partial last sweep; M = 33: a one-row unit."""
+    lib = L.load()
+    E, F = 256, 512
+    g = torch.Generator().manual_seed(M + 23)
+    dr2 = rnd(g, M, E)
+    dres2 = bf(rnd(g, M, E)).float()
+    W1, W2, Wo = bf(rnd(g, F, E, scale=0.06)).float(), bf(rnd(g, E, F, scale=0.05)).float(), bf(rnd(g, E, E, scale=0.06)).float()
+    r1 = bf(rnd(g, M, E)).float()
+    g1 = 1 + rnd(g, E, scale=0.1)
+    hid = bf((rnd(g, M, F)).clamp_min(0) * (torch.rand(M, F, generator=g) > 0.1)).float()        # ReLU output with dropped entries
+    drop = (0.1, 31, 1013, 1011, 4) if drop_on else (0.0, 0, 0, 0, 0)
+    ks = keep_scale(drop[0]) if drop_on else 1.0
+    mu = r1.double().mean(-1, keepdim=True)
+    st1 = torch.cat([mu, 1.0 / torch.sqrt(((r1.double() - mu) ** 2).mean(-1, keepdim=True) + 1e-5)], 1)
+    d = lambda t, dt=torch.float32: t.to(DEV, dt).contiguous()
+    dx_d = d(dr2)
+    Wcat = d(torch.cat([W1.reshape(-1), W2.reshape(-1), Wo.reshape(-1)]))
+    dres2_d, r1_d, h_d = d(dres2, torch.bfloat16), d(r1, torch.bfloat16), d(hid, torch.bfloat16)
+    st1_d, g1_d = d(st1.float()), d(g1)
+    nan16 = lambda *s: torch.full(s, float("nan"), dtype=torch.bfloat16, device=DEV)
+    dh_d, dres1_d, dctx_d = nan16(M, F), nan16(M, E), nan16(M, E)
+    cs_d = torch.zeros(3, E, device=DEV)
+    wf = torch.empty(lib.gg_test_enc_bwd_frag_bytes(), dtype=torch.uint8, device=DEV)
+    L.check(lib.gg_test_enc_bwd(P(dx_d), M, P(Wcat), P(dres2_d), P(h_d), P(r1_d), P(st1_d), P(g1_d), P(dh_d), P(dres1_d), P(dctx_d), P(cs_d),
+                                C.c_float(drop[0]), drop[1], drop[3], drop[4], P(wf), stream()))
+    torch.cuda.synchronize()
+    diag(f"== fused encoder-layer backward M={M} dropout={drop_on}")
+    st1f = st1.float().double()
+    W1d, W2d, Wod = W1.double(), W2.double(), Wo.double()
+    sums = torch.zeros(3, E, dtype=torch.float64)
+    worst = {}
+
+    def acc(name, got, want, bfo, l2b=None, mxb=None):
+        got = got.detach().cpu()
+        assert torch.isfinite(got.float()).all(), name
+        l2, mx = rel_l2(got, want), rel_max(got, want)
+        w = worst.setdefault(name, [0.0, 0.0])
+        w[0], w[1] = max(w[0], l2), max(w[1], mx)
+        assert l2 <= (l2b or (2e-3 if bfo else 1e-4)) and mx <= (mxb or (2.0 ** -8 if bfo else 2e-4)), (name, l2, mx)
+    chunk = 16384
+    for a in range(0, M, chunk):
+        b = min(M, a + chunk)
+        m1 = 1.0
+        if drop_on:
+            k0, thr = drop_key(drop[0], drop[1], drop[3], drop[4])
+            m1 = torch.from_numpy(drop_keep(k0, thr, np.arange(a * E, b * E, dtype=np.int64)).reshape(b - a, E)).double() * ks
+        dh = (dres2[a:b].double() @ W2d) * (hid[a:b].double() > 0) * ks
+        dx1 = dr2[a:b].double() + bf(dh.float()) @ W1d
+        st = st1f[a:b]
+        xh = (r1[a:b].double() - st[:, :1]) * st[:, 1:]
+        gy = dx1 * g1.double()
+        dr1 = st[:, 1:] * (gy - gy.mean(-1, keepdim=True) - xh * (gy * xh).mean(-1, keepdim=True))
+        dres1 = dr1 * m1
+        dctx = bf(dres1.float()) @ Wod
+        for i, v in enumerate(((dx1 * xh).sum(0), dx1.sum(0), dres1.sum(0))):
+            sums[i] += v
+        acc("dh (bf16)", dh_d[a:b], dh, True, None, 2.0 ** -7)
+        acc("dres1 (bf16)", dres1_d[a:b], dres1, True, None, 2.0 ** -7)
+        acc("dctx (bf16)", dctx_d[a:b], dctx, True, None, 2.0 ** -7)
+        # dr1 carries the bf16 rounding of dh through a 512-term product: 2^-9 / sqrt(512) per term relative to the branch, ~1e-4 of dr1
+        acc("dr1 over dr2 (fp32)", dx_d[a:b], dr1, False, 5e-4, 2e-3)
+    for k, v in worst.items():
+        diag(f"   {k:44s} rel-L2 {v[0]:.2e}  max-norm {v[1]:.2e}")
+    for i, nm in enumerate(("dgamma1", "dbeta1", "d out_proj.bias")):
+        check(nm, cs_d[i], sums[i], False, 2e-3, 4e-3)      # sums of M terms of either sign whose inputs carry the bf16 rounding of dh
