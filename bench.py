@@ -82,7 +82,22 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-PMC_SUMMARIES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_SUMMARIES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+SIDE_STREAM_FAMILIES = ("wgrad_kernel",)     # parameter-gradient kernels: launched on the engine's side stream, off the main chain
+
+
+def family(name):
+    """Kernel family of a profile class: the kernel's name without its template arguments."""
+    return name.split("<")[0]
+
+
+def fam_sum(rows, fam):
+    """One row for a whole family: times, launches and algorithmic work of its instantiations added up."""
+    rs = [r for r in rows if family(r["name"]) == fam and r["launches"] > 0]
+    if not rs:
+        return None
+    return dict(name=fam, launches=sum(r["launches"] for r in rs), ms=sum(r["ms"] for r in rs), flops=sum(r["flops"] for r in rs),
+                bytes=sum(r["bytes"] for r in rs), instantiations=len(rs))
 
 
 def pmc_source():
@@ -323,10 +338,17 @@ def main():
     if world > 1:
         w.comm_wait_ms()                          # drop the warm-up's event pairs
     if prof:
-        # The timed region carries event pairs for the DOMINANT class only (live roofline over the timed steps): an event
-        # pair around each of the ~600 GEMM-class launches of a step costs 3 ms per step on the host-fed stream.
-        dom_cls = max(rows_all, key=lambda r: r["ms"])["name"] if rows_all else None
-        w.engine.profile(True, [dom_cls] if dom_cls else None)
+        # The timed region carries event pairs for the DOMINANT family and the side-stream family only (live roofline over the
+        # timed steps): an event pair around each of the ~600 GEMM-class launches of a step costs 3 ms per step on the host-fed stream.
+        # Nominated by FAMILY (all instantiations of one kernel template added up) over the kernels of the main chain; the
+        # parameter-gradient family runs on the side stream beside that chain and is reported as `side_stream`.
+        fams = {}
+        for r in rows_all:
+            fams[family(r["name"])] = fams.get(family(r["name"]), 0.0) + r["ms"]
+        main_fams = {k: v for k, v in fams.items() if k not in SIDE_STREAM_FAMILIES}
+        dom_fam = max(main_fams, key=main_fams.get) if main_fams else (max(fams, key=fams.get) if fams else None)
+        live_cls = [r["name"] for r in rows_all if family(r["name"]) == dom_fam or family(r["name"]) in SIDE_STREAM_FAMILIES]
+        w.engine.profile(True, live_cls if live_cls else None)
     prof_steps = min(2, args.steps)               # timed steps that carry the event pairs (a host-side flag, no sync)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -340,6 +362,23 @@ def main():
         rows = w.engine.profile_collect()
         w.engine.profile(False)
     launches_per_step = w.engine.launch_count()        # of the last timed step (the parity-mode leg below has its own count)
+    phases = None
+    if not args.no_profile:
+        # one more, untimed step with the engine's phase marks on (an event per phase boundary of train(), ~35 per step, no
+        # serialisation): the un-profiled timeline of the step, side streams and all.  Every rank runs it (it holds collectives).
+        w.engine.phase_enable(True)
+        train_once()
+        torch.cuda.synchronize(dev)
+        marks = w.engine.phase_times()
+        w.engine.phase_enable(False)
+        kinds = {}
+        for name, pms in marks:
+            kinds[name] = kinds.get(name, 0.0) + pms
+        phases = {"marks": len(marks), "ms_total": round(sum(kinds.values()), 3),
+                  "ms_by_phase": {k: round(v, 3) for k, v in kinds.items()},
+                  "note": "milliseconds between the engine's phase marks (include/gemmgan.h gg_phase_*) on the main stream over one "
+                          "untimed step after the timed region, summed per phase kind over the 5 critic iterations + the generator "
+                          "iteration; a phase's time includes waiting for side-stream work it joins"}
     graph_stats = w.engine.graph_stats() if w.engine.graph else None
     comm_ms = w.comm_wait_ms() / args.steps if world > 1 else 0.0
     t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
@@ -406,49 +445,73 @@ def main():
             out["parity_mode"] = parity
         if rows:
             rows = [r for r in rows if r["launches"] > 0]
-            dom = max(rows, key=lambda r: r["ms"])
+            dom = fam_sum(rows, dom_fam) or max(rows, key=lambda r: r["ms"])
+            members = [r for r in rows if family(r["name"]) == dom["name"]] or [dom]
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             # fp8 mode: only the e4m3 Linear instantiations (last template argument `true`) are priced against the fp8 peak;
             # attention, weight gradients and LayerNorm run their MFMAs in bf16 in that mode too
-            fp8_kernel = args.precision == "fp8" and (dom["name"].startswith(("tlin_", "wst_")) and dom["name"].rstrip(">").endswith("true"))
+            fp8_kernel = args.precision == "fp8" and dom["name"].startswith(("tlin_", "wst_")) and \
+                all(r["name"].rstrip(">").endswith("true") for r in members)
             peak_tf = PEAK_TFLOPS["fp8"] if fp8_kernel else PEAK_TFLOPS["f32" if args.precision == "f32" else "bf16"]
             frac_m, frac_h = tf / peak_tf, gbs / PEAK_HBM_GBS
-            # which roof: the kernel's arithmetic intensity against the machine's ridge point (FLOP per HBM byte)
+            # which roof: the family's arithmetic intensity against the machine's ridge point (FLOP per HBM byte)
             intensity = dom["flops"] / max(dom["bytes"], 1.0)
             ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
             bound = "mfma" if intensity >= ridge else "hbm"
             traffic = pmc_traffic(dom["name"])
-            iso = None
-            for r in rows_all:
-                if r["name"] == dom["name"]:
-                    ig = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-                    it = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                    iso = {"achieved": round(it if bound == "mfma" else ig, 2),
-                           "frac": round(it / peak_tf if bound == "mfma" else ig / PEAK_HBM_GBS, 4),
-                           "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches": r["launches"]}
+
+            def priced(r, b):
+                ig = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                it = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                return {"achieved": round(it if b == "mfma" else ig, 2),
+                        "frac": round(it / peak_tf if b == "mfma" else ig / PEAK_HBM_GBS, 4),
+                        "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches": r["launches"]}
+            iso_row = fam_sum(rows_all, dom["name"])
+            iso = priced(iso_row, bound) if iso_row else None
+            side = []
+            for f in SIDE_STREAM_FAMILIES:
+                live, ser = fam_sum(rows, f), fam_sum(rows_all, f)
+                if live is None:
+                    continue
+                sb = "mfma" if live["flops"] / max(live["bytes"], 1.0) >= ridge else "hbm"
+                side.append({"kernel": f, "instantiations": live["instantiations"], "bound": sb,
+                             "unit": "TFLOP/s" if sb == "mfma" else "GB/s", **priced(live, sb),
+                             "algorithmic_bytes_per_launch": round(live["bytes"] / live["launches"]), "traffic": pmc_traffic(f),
+                             "isolated": priced(ser, sb) if ser else None,
+                             "ms_per_step_live": round(live["ms"] / prof_steps, 3),
+                             "note": "launched on the engine's side stream beside the main chain: the live duration of a launch includes "
+                                     "waiting for the compute units and HBM bandwidth the main chain holds, so its live sum is not time "
+                                     "on the step's critical path; `isolated` is the serialised warm-up step"})
             out["roofline"] = {"kernel": dom["name"], "bound": bound,
                                "achieved": round(tf if bound == "mfma" else gbs, 2),
                                "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
                                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                "frac": round(frac_m if bound == "mfma" else frac_h, 4), "traffic": traffic,
                                "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
-                               "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes, "
+                               "traffic_note": "HBM bytes per launch (launch-weighted mean over the family) from rocprofv3 PMC "
+                                               "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes, "
                                                f"profiles/{pmc_source()}; algorithmic bytes per launch = "
                                                + str(round(dom["bytes"] / dom["launches"] / 1e6, 1)) + " MB",
                                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": dom["launches"],
                                "share_of_step": round(dom["ms"] / (dt * 1e3 * prof_steps / args.steps), 3),
                                "timed_steps_with_events": prof_steps,
-                               "note": "the kernel with the largest total time in a step with the engine's streams serialised, over ALL "
-                                       "heavy kernels - Linears, weight gradients, attention forward / dQ / dK|dV, LayerNorm backward, "
-                                       "small GEMMs per instantiation (classes carry the kernels' own names, as rocprofv3 prints "
-                                       "them); `bound` is the side of the ridge its algorithmic FLOP/byte falls on - the attention "
-                                       "kernels are in fact VALU-bound (exp2, dropout hash, conversions: ~25 ops per score), see "
-                                       "profiles/r03_pmc_mfma.json; achieved / frac are "
-                                       "live over the timed region, where it shares the chip with the parameter-gradient / prefetch "
-                                       "kernels of the side streams; `isolated` is the same kernel in the serialised warm-up step. "
-                                       "The weight-gradient kernels run on the engine's side stream beside the main chain: their live "
-                                       "durations include waiting for compute units and HBM bandwidth the main chain holds",
+                               "instantiations": [{"name": r["name"], "launches": r["launches"],
+                                                   "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                                                   "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
+                                                   "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
+                                                   "traffic": pmc_traffic(r["name"])} for r in members],
+                               "side_stream": side,
+                               "note": "nominated by kernel FAMILY: the kernel template whose instantiations add up to the largest time on "
+                                       "the step's main chain in a step with the engine's streams serialised (classes carry the kernels' "
+                                       "own names, as rocprofv3 prints them; `instantiations` lists them, `achieved` = the family's "
+                                       "algorithmic bytes or FLOPs / the sum of its launch durations, by HIP events on the launching "
+                                       "stream); the parameter-gradient kernels run on the side stream and are `side_stream`, not "
+                                       "candidates. `bound` is the side of the ridge the family's algorithmic FLOP/byte falls on - the "
+                                       "attention kernels are in fact VALU-bound (exp2, dropout hash, conversions), see "
+                                       "profiles/r04_pmc_mfma.json; achieved / frac are live over the timed region, where the family "
+                                       "shares the chip with the side streams' kernels; `isolated` is the same family in the serialised "
+                                       "warm-up step",
                                "isolated": iso,
                                "gp_chain": gp_rows,
                                "gp_chain_note": "gradient-penalty kernels (R:351-374 closed form + double backward, 6 launches per critic "
@@ -481,6 +544,7 @@ def main():
                 "ideal_ms_mfma": round(fl / (peak_tf_step * 1e12) * 1e3, 3), "ideal_ms_hbm": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 3),
                 "pmc_hbm_bytes": pmc_b, "pmc_source": pmc_f,
                 "pmc_over_algorithmic": round(pmc_b / by, 2) if pmc_b else None,
+                "phases": phases,
                 "frac_hbm_on_pmc_bytes": round(pmc_b / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pmc_b else None,
                 "note": "algorithmic = SURVEY.md 8(d) formulas (FLOPs = 2 x MACs of the reference's necessary work; bytes = gradient-"
                         "penalty chain + raw patch stream in fp32); pmc = sum over the heavy kernels of launches x (2*FETCH_SIZE + "
@@ -491,7 +555,11 @@ def main():
             out["roofline_step"] = step
         if world > 1:
             out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
-                                           "buckets_per_optimizer_step": 2, "optimizer_steps_per_train": 6}
+                                           "buckets_per_optimizer_step": 1 if vanilla else 1 + getattr(w.engine, "cond_stages", 0),
+                                           "optimizer_steps_per_train": 6,
+                                           "note": "one all-reduce per backward stage, issued from the side stream the moment that "
+                                                   "stage's gradients are final (MLP; then cross-attention, encoder layers last to "
+                                                   "first, patch/text front), reduced under the stages still running"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -166,6 +166,7 @@ SYMBOLS = {
     "gg_phase_read": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "gg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gg_profile_enable_class": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gg_profile_add_class": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gg_profile_collect": (C.c_int, [C.c_void_p]),
     "gg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),

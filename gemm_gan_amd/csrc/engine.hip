@@ -233,7 +233,7 @@ struct gg_engine {
     // instantiation): registered by name on first use, ids 64 + index; taken with the full mask or when singled out
     std::vector<std::string> named_cls;
     bool prof_named_all = true;
-    int prof_named_one = -1;
+    std::vector<bool> prof_named_sel;      // named classes (id 64 + i) that get event pairs when prof_named_all is off
     int str_cls[40] = {0};          // tlin_str_kernel<256,XB,YB,EPI> instantiation -> profiling class id (0: none yet)
     int n_str_cls = 0;
     std::string str_cls_name[14];
@@ -499,7 +499,8 @@ int named_class(gg_engine* e, const char* name) {
 }
 inline bool prof_wanted(const gg_engine* e, int cls) {
     if (!e->prof_on) return false;
-    return cls < 64 ? ((e->prof_mask >> cls) & 1u) != 0 : (e->prof_named_all || e->prof_named_one == cls);
+    return cls < 64 ? ((e->prof_mask >> cls) & 1u) != 0
+                    : (e->prof_named_all || ((size_t)(cls - 64) < e->prof_named_sel.size() && e->prof_named_sel[(size_t)(cls - 64)]));
 }
 // event pair around a launch of a named class (the kernels taken this way run for >= tens of microseconds, or are counted
 // only in the serialised all-classes step)
@@ -2587,24 +2588,40 @@ int gg_profile_enable(gg_engine* e, int on) {
     e->prof_on = on != 0;
     e->prof_mask = on > 1 ? (unsigned)on >> 1 : 0xffffffffu;      // on = 1 | (class bit mask << 1) restricts the classes
     e->prof_named_all = on == 1;
-    e->prof_named_one = -1;
+    e->prof_named_sel.clear();
     if (on) { e->prof_recs.clear(); e->prof_next = 0; }
     return 0;
 }
-// event pairs for exactly one class, by the name gg_profile_read reported for it
-int gg_profile_enable_class(gg_engine* e, const char* name) {
-    GG_REQUIRE(e && name, "null argument");
-    e->prof_mask = 0; e->prof_named_all = false; e->prof_named_one = -1;
+// event pairs for the named class only (add = 0), or for it as well as the classes already selected (add = 1); names as
+// gg_profile_read reported them
+namespace {
+int profile_select_class(gg_engine* e, const char* name, bool add) {
+    if (!add) { e->prof_mask = 0; e->prof_named_sel.clear(); }
+    e->prof_named_all = false;
     bool found = false;
     for (size_t i = 0; i < e->named_cls.size() && !found; ++i)
-        if (e->named_cls[i] == name) { e->prof_named_one = 64 + (int)i; found = true; }
+        if (e->named_cls[i] == name) {
+            if (e->prof_named_sel.size() <= i) e->prof_named_sel.resize(i + 1, false);
+            e->prof_named_sel[i] = true; found = true;
+        }
     const size_t fixed = std::min<size_t>(32, 18 + (size_t)e->n_str_cls);       // prof_agg = fixed ids, Linear ids, named classes
     for (size_t i = 0; i < e->prof_agg.size() && i < fixed && !found; ++i)
-        if (e->prof_agg[i].name == name) { e->prof_mask = 1u << i; found = true; }
+        if (e->prof_agg[i].name == name) { e->prof_mask |= 1u << i; found = true; }
     GG_REQUIRE(found, "gg_profile_enable_class: unknown class (names come from gg_profile_read after a full collect)");
+    return 0;
+}
+}  // namespace
+int gg_profile_enable_class(gg_engine* e, const char* name) {
+    GG_REQUIRE(e && name, "null argument");
+    GG_TRY(profile_select_class(e, name, false));
     e->prof_on = true;
     e->prof_recs.clear(); e->prof_next = 0;
     return 0;
+}
+int gg_profile_add_class(gg_engine* e, const char* name) {
+    GG_REQUIRE(e && name, "null argument");
+    GG_REQUIRE(e->prof_on && !e->prof_named_all, "gg_profile_add_class: call gg_profile_enable_class first");
+    return profile_select_class(e, name, true);
 }
 int gg_profile_collect(gg_engine* e) {
     if (!e) return -1;

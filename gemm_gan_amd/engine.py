@@ -374,8 +374,9 @@ class Engine:
     def profile(self, on: bool, classes=None):
         """HIP-event pair around every GEMM-class launch (classes=None) or only around the named classes."""
         if on and classes:
-            assert len(classes) == 1, "one class at a time (names as profile_collect reports them)"
-            L.check(self.lib.gg_profile_enable_class(self.h, classes[0].encode()))
+            L.check(self.lib.gg_profile_enable_class(self.h, classes[0].encode()))      # names as profile_collect reports them
+            for name in classes[1:]:
+                L.check(self.lib.gg_profile_add_class(self.h, name.encode()))
             return
         arg = int(bool(on))
         L.check(self.lib.gg_profile_enable(self.h, arg))

@@ -341,6 +341,7 @@ int gg_phase_count(const gg_engine* e);
 int gg_phase_read(gg_engine* e, int index, char* name, int name_cap, double* ms);
 int gg_profile_enable(gg_engine* e, int on);
 int gg_profile_enable_class(gg_engine* e, const char* name);   /* event pairs for ONE class, by its gg_profile_read name */
+int gg_profile_add_class(gg_engine* e, const char* name);      /* ... and for this class as well (after gg_profile_enable_class) */
 int gg_profile_collect(gg_engine* e);            /* returns number of classes, <0 on error */
 int gg_profile_read(gg_engine* e, int index, char* name, int name_cap, int64_t* launches, double* ms,
                     double* flops, double* bytes);
