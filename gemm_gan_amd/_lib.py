@@ -107,6 +107,7 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p]),
     "gg_test_ffn2_frag_bytes": (C.c_int64, []),
+    "gg_test_set_enc_grid": (C.c_int, [C.c_int]),
     "gg_test_ffn2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_void_p, C.c_int, C.c_void_p]),

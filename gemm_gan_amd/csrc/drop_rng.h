@@ -38,6 +38,7 @@ __device__ __forceinline__ DropKey drop_live(DropKey k) {
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
         k.k0 = h;
     }
+    k.k0 += k.post;
     return k;
 }
 // pre-mix state of element pair `pair` (= element index >> 1)

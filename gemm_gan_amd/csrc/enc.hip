@@ -906,16 +906,26 @@ bool ffn2_supported(const Ffn2P& p) {
     return true;
 }
 
-int ffn2(const Ffn2P& p, hipStream_t st, int variant) {
-    GG_REQUIRE(ffn2_supported(p), "ffn2: unsupported operands");
+namespace {
+int g_grid_override = 0;
+long enc_grid_cus() {
+    if (g_grid_override > 0) return g_grid_override;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
-        GG_CHECK_HIP(hipGetDevice(&dev));
-        GG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+        if (n_cu <= 0) return 256;
     }
     static const int cu_pct = getenv("GG_ENC_CU_PCT") ? atoi(getenv("GG_ENC_CU_PCT")) : 100;
-    const long cus = std::max<long>(8, (long)n_cu * cu_pct / 100);
+    return std::max<long>(8, (long)n_cu * cu_pct / 100);
+}
+}  // namespace
+void enc_set_grid(int workgroups) { g_grid_override = workgroups > 0 ? workgroups : 0; }
+long ffn2_sweep_tokens(int variant) { return enc_grid_cus() * 32 * (variant >= 4 ? 4 : 8); }
+
+int ffn2(const Ffn2P& p, hipStream_t st, int variant) {
+    GG_REQUIRE(ffn2_supported(p), "ffn2: unsupported operands");
+    const long cus = enc_grid_cus();
     const bool drop = p.drop1.p > 0.f;
     GG_REQUIRE(drop == (p.drop2.p > 0.f), "ffn2: the two dropout sites are on or off together");
     if (p.stamps) {

@@ -191,7 +191,12 @@ struct gg_engine {
     float *s_dqt, *s_dxbar;
     int tlin_on = 1;           // use the token-on-lane Linear kernels when precision == bf16 and the shape allows
     int encb_on = getenv("GG_ENCB") ? atoi(getenv("GG_ENCB")) : 0;     // fused backward of the token-local chain behind LayerNorm2's backward (enc.hip encb_kernel)
-    int ffn2_on = getenv("GG_FFN2") ? atoi(getenv("GG_FFN2")) : 0;     // 1 + variant: the streamed fused feed-forward block (enc.hip) in bf16 mode with bf16-stored LayerNorm outputs
+    // 1 + variant: the streamed fused feed-forward block (enc.hip) in bf16 mode with bf16-stored LayerNorm outputs.  Opt-in: it takes the
+    // whole passes of its persistent grid and leaves the R * B rows past them to the two Linear launches, so WHICH kernel computes a row
+    // depends on the row's position in the batch - the two agree to bf16 rounding ties only (6e-3 on activations), and the full-size
+    // row-independence / shard-identity properties of tests/test_engine_oracle_gpu.py then hold to 7e-3 instead of 1e-3.  Not worth
+    // 0.19 ms of a 24.9 ms step (profiles/r04_ab_notes.md).
+    int ffn2_on = getenv("GG_FFN2") ? atoi(getenv("GG_FFN2")) : 0;
     int ffn_on = getenv("GG_FFN_FUSED") != nullptr;   // fused feed-forward block (ffn.hip), bf16 mode, E = 256: opt-in (or gg_set_ffn_fused) -
                                // measured 20 % slower than the two launches it replaces (profiles/r03_ffn_fused.md)
     float *s_dt, *s_dp, *s_dq, *s_dq2, *s_dkv, *s_dkv2, *s_dtokrep, *s_dtok, *s_dtok0, *s_dx0, *s_demb, *s_mod, *s_dmod, *s_dgb, *s_tmpE;
@@ -668,7 +673,7 @@ int refresh_shadows(Ctx& c, Net& n) {
         return 0;
     }
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
-    if (c.e->ffn2_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {
+    if (c.e->ffn2_on && !c.e->fp8_fwd && c.e->bstore_on && c.e->xstore_on && c.e->rstore_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {      // cond_forward's streamed-FFN route
         long o1[MAXL], o2[MAXL];
         for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; }
         KL(k_enc_frag_weights(n.w, o1, o2, c.e->nl, n.wfrag, c.st));
@@ -993,47 +998,70 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
                 ffn_done = true;
             }
         }
-        if (!ffn_done && xst && rst && !e->fp8_fwd && e->ffn2_on && E == 256 && F == 512) {   // the streamed form (enc.hip): bf16 x1 in, weights as MFMA fragments through an LDS ring
-            Ffn2P f;
-            f.X = L.x1; f.M = RB * S; f.Wf = n.wfrag + (size_t)l * enc_frag_bytes(1);
-            f.b1 = w + lp.l1b; f.b2 = w + lp.l2b; f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b;
-            f.Hs = L.h; f.R2 = L.r2; f.r2_bf16 = 1; f.stats = L.st2; f.Y = L.x2; f.y_bf16 = l + 1 < e->nl; f.keep_rows = keep_rows;
-            f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
-            if (ffn2_supported(f) && (f.drop1.p > 0.f) == (f.drop2.p > 0.f)) {
-                const double tokd = (double)RB * S, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
-                ProfScope ps(c, "ffn2_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (2.0 * E + (f.y_bf16 ? 2.0 : 4.0) * E) + kept * (2.0 * F + 2.0 * E + 8.0) + 4.0 * E * F);
-                KL(ffn2(f, c.st, e->ffn2_on - 1));
-                ffn_done = true;
-            }
-        }
-        if (!ffn_done) {
+        // rows [r0, r0 + Mt) of the block through the two Linear launches (the whole block, or the rows the streamed kernel leaves)
+        auto ffn_two_launches = [&](long r0, long Mt) -> int {
+            auto at = [](const void* ptr, long elems, bool bf16) { return static_cast<const char*>(ptr) + elems * (bf16 ? 2 : 4); };
+            auto rows_key = [&](DropKey k, long ld) {       // the stream words of rows r0.. with row indices local to the launch (kernels.h DropKey::post)
+                k.post = (uint32_t)(((uint64_t)r0 * (uint64_t)ld) >> 1) * 0x9E3779B1u;
+                return k;
+            };
+            const long keep_t = keep_rows < 0 ? -1 : std::max<long>(0, std::min<long>(Mt, keep_rows - r0));
+            const bool x2b = xst && l + 1 < e->nl;
             {   // h = drop(relu(x1 W1^T + b1))
                 TlinP t;
-                t.X = L.x1; t.ldx = E; t.M = RB * S; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
-                t.Y = L.h; t.ldy = F; t.N = F; t.K = E; t.act_relu = 1; t.drop = dkey(e, a, n.role, l, 2); t.drop_ld = F;
+                t.X = at(L.x1, r0 * E, xst); t.ldx = E; t.M = Mt; t.W = WB(n, lp.l1w); t.ldw = E; t.bias = w + lp.l1b;
+                t.Y = const_cast<char*>(at(L.h, r0 * F, bst)); t.ldy = F; t.N = F; t.K = E; t.act_relu = 1;
+                t.drop = rows_key(dkey(e, a, n.role, l, 2), F); t.drop_ld = F;
                 t.y_bf16 = bst; t.x_bf16 = xst;
                 if (bst) maybe_fp8(e, n, t, lp.l1w);
                 if (bst) TLIN_MUST(t);
                 else TLIN_OR(t, {
-                    GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)(RB * S), F, E, ACT_LRELU, 0.f));
-                    if (drop > 0.f) KL(k_dropout(L.h, RB * S * F, dkey(e, a, n.role, l, 2), c.st));
+                    GG_TRY(lin_fwd(c, L.x1, E, w + lp.l1w, E, w + lp.l1b, L.h, F, (int)Mt, F, E, ACT_LRELU, 0.f));
+                    if (drop > 0.f) KL(k_dropout(L.h, Mt * F, dkey(e, a, n.role, l, 2), c.st));
                 });
             }
             {   // x2 = LN2(x1 + drop(h W2^T + b2))
                 TlinP t;
-                t.X = L.h; t.ldx = F; t.M = RB * S; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
-                t.Y = L.r2; t.ldy = E; t.N = E; t.K = F; t.drop = dkey(e, a, n.role, l, 3); t.drop_ld = E;
-                t.res = L.x1; t.ldres = E; t.res_rows = RB * S; t.y_rows = keep_rows;
-                t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b; t.ln_y = L.x2; t.ln_stats = L.st2; t.x_bf16 = bst;
-                t.res_bf16 = xst; t.ln_y_bf16 = xst && l + 1 < e->nl; t.y_bf16 = rst;
+                t.X = at(L.h, r0 * F, bst); t.ldx = F; t.M = Mt; t.W = WB(n, lp.l2w); t.ldw = F; t.bias = w + lp.l2b;
+                t.Y = const_cast<char*>(at(L.r2, r0 * E, rst)); t.ldy = E; t.N = E; t.K = F;
+                t.drop = rows_key(dkey(e, a, n.role, l, 3), E); t.drop_ld = E;
+                t.res = reinterpret_cast<const float*>(at(L.x1, r0 * E, xst)); t.ldres = E; t.res_rows = Mt; t.y_rows = keep_t;
+                t.ln_g = w + lp.n2w; t.ln_b = w + lp.n2b;
+                t.ln_y = reinterpret_cast<float*>(const_cast<char*>(at(L.x2, r0 * E, x2b))); t.ln_stats = L.st2 + 2 * r0; t.x_bf16 = bst;
+                t.res_bf16 = xst; t.ln_y_bf16 = x2b; t.y_bf16 = rst;
                 if (bst) maybe_fp8(e, n, t, lp.l2w);
                 if (bst) TLIN_MUST(t);
                 else TLIN_OR(t, {
-                    GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)(RB * S), E, F));
-                    KL(k_add_layernorm_fwd(L.x1, RB * S, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, RB * S, E, dkey(e, a, n.role, l, 3), c.st));
+                    GG_TRY(lin_fwd(c, L.h, F, w + lp.l2w, F, w + lp.l2b, L.r2, E, (int)Mt, E, F));
+                    KL(k_add_layernorm_fwd(L.x1, Mt, L.r2, w + lp.n2w, w + lp.n2b, L.x2, L.st2, Mt, E, dkey(e, a, n.role, l, 3), c.st));
                 });
             }
+            return 0;
+        };
+        if (!ffn_done && xst && rst && !e->fp8_fwd && e->ffn2_on && E == 256 && F == 512) {   // the streamed form (enc.hip): bf16 x1 in, weights as MFMA fragments through an LDS ring
+            // The streamed kernel is persistent, one workgroup per compute unit: M = R * B * 257 tokens is a whole number of passes of
+            // the grid plus R * B rows (the CLS token), and those rows would cost every launch one more pass on a nearly empty chip
+            // (measured: 145 us at 3 * 65 536 rows, 175 us at 3 * 65 792).  It takes the whole passes; the few rows left over go through
+            // the two Linear launches (rows are independent in this block).
+            const long Mtot = RB * S, sweep = ffn2_sweep_tokens(e->ffn2_on - 1);
+            long Mmain = Mtot / sweep * sweep;
+            if (Mmain == 0 || (Mtot - Mmain) * 8 > sweep) Mmain = Mtot;            // no full pass, or a left-over worth a pass of its own
+            Ffn2P f;
+            f.X = L.x1; f.M = Mmain; f.Wf = n.wfrag + (size_t)l * enc_frag_bytes(1);
+            f.b1 = w + lp.l1b; f.b2 = w + lp.l2b; f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b;
+            f.Hs = L.h; f.R2 = L.r2; f.r2_bf16 = 1; f.stats = L.st2; f.Y = L.x2; f.y_bf16 = l + 1 < e->nl; f.keep_rows = keep_rows;
+            f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
+            if (ffn2_supported(f) && (f.drop1.p > 0.f) == (f.drop2.p > 0.f)) {
+                const double tokd = (double)Mmain, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
+                {
+                    ProfScope ps(c, "ffn2_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (2.0 * E + (f.y_bf16 ? 2.0 : 4.0) * E) + kept * (2.0 * F + 2.0 * E + 8.0) + 4.0 * E * F);
+                    KL(ffn2(f, c.st, e->ffn2_on - 1));
+                }
+                if (Mmain < Mtot) GG_TRY(ffn_two_launches(Mmain, Mtot - Mmain));
+                ffn_done = true;
+            }
         }
+        if (!ffn_done) GG_TRY(ffn_two_launches(0, RB * S));
         x_in = L.x2;
     }
     if (!e->xattn) {    // conditioning vector = the encoder's CLS row (conditional_gan_film.py:150)
@@ -1117,8 +1145,10 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
 // OVERWRITES a buffer the pending launch reads (slot 0: sdres, 1: sdh, 2: sdqkv; 3: head / gradient-penalty parameter
 // gradients, whose operands live until the next iteration; 4: the second bf16 image in sdres, LN1's branch gradient when the
 // fused += / LayerNorm-backward kernel writes it) and at the end of the backward.
-// The engine's own streams run at the default priority: A/B runs with the device's lowest / highest stream priority
-// (GG_SIDE_PRIO=low|high) measured 38.4 / 39.0 ms per step against 38.2 at the default.
+// Streams the ENGINE creates (a C host that binds none with gg_bind_streams): default priority, or with GG_SIDE_PRIO=low|high in the
+// environment the device's lowest / highest one (A/B runs measured 38.4 / 39.0 ms per step against 38.2 at the default, DESIGN.md
+// section 3).  The Python host binds two torch streams instead (engine.py: default priority; GG_SIDE_PRIO=high asks torch for its
+// high-priority pool, any other value means the default) and this function is then never reached.
 bool create_side_stream(hipStream_t* s) {
     const char* pr = getenv("GG_SIDE_PRIO");
     int least = 0, greatest = 0;

@@ -448,7 +448,7 @@ int k_gp_grad(const float* g1, const float* W1, long ldw, float* grad, float* nr
 }
 int k_gp_coef_scale(const float* nrm2, const float* g1, float* coef, float* g1s, float* loss, int B, int H, float gp_weight,
                     hipStream_t st, int nparts, float* nrm2_total) {
-    launch(gp_coef_k, dim3((B + 3) / 4), 0, st, nrm2, g1, coef, g1s, loss, B, H, gp_weight, nparts, nparts > 1 ? nrm2_total : (float*)nullptr);
+    launch(gp_coef_k, dim3((B + 3) / 4), 0, st, nrm2, g1, coef, g1s, loss, B, H, gp_weight, nparts, nrm2_total != nrm2 ? nrm2_total : (float*)nullptr);      // the row totals always land in nrm2_total (one strip: a copy)
     GP_LAUNCH_CHECK();
 }
 int k_gp_tail(const float* dg1pre, const float* coef, const float* a1, const float* a2, const float* w3, const float* W2, float* dW2,

@@ -245,19 +245,21 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 bool head_fused_supported(const HeadP& p) {
     if (p.rows < 1 || p.H < 32 || p.H > HMAX || p.H % 32 || p.E < 16 || p.E > 256 || p.E % 32 || p.ldw1 % 4) return false;
     if (!p.W1c || !p.W2 || !p.a1 || !p.a2 || !al16(p.W1c) || !al16(p.W2) || !al16(p.a1) || !al16(p.a2)) return false;
+    // every operand the forward / backward launch reads 16 bytes at a time, when given: the engine falls back to the Linear chain
+    // on a flat-buffer offset that misses the alignment instead of failing the step in head_fwd / head_bwd
+    if (!al16(p.cvec) || !al16(p.b1) || !al16(p.b2) || !al16(p.w3) || !al16(p.dh1) || !al16(p.dh2) || !al16(p.dcond)) return false;
     return true;
 }
 int head_fwd(const HeadP& p, hipStream_t st) {
-    GG_REQUIRE(head_fused_supported(p) && p.cvec && p.b1 && p.b2 && al16(p.cvec) && al16(p.b1) && al16(p.b2), "head_fwd: unsupported operands");
-    GG_REQUIRE(!p.out || (p.w3 && p.b3 && al16(p.w3)), "head_fwd: the score column needs w3 / b3");
+    GG_REQUIRE(head_fused_supported(p) && p.cvec && p.b1 && p.b2, "head_fwd: unsupported operands");
+    GG_REQUIRE(!p.out || (p.w3 && p.b3), "head_fwd: the score column needs w3 / b3");
     head_fwd_k<<<(unsigned)((p.rows + 31) / 32), 512, 0, st>>>(p);
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int head_bwd(const HeadP& p, hipStream_t st) {
-    GG_REQUIRE(head_fused_supported(p) && p.dh2 && p.dh1 && al16(p.dh2) && al16(p.dh1), "head_bwd: unsupported operands");
-    GG_REQUIRE(!p.dout || (p.w3 && al16(p.w3)), "head_bwd: dout needs w3");
-    GG_REQUIRE(!p.dcond || al16(p.dcond), "head_bwd: misaligned dcond");
+    GG_REQUIRE(head_fused_supported(p) && p.dh2 && p.dh1, "head_bwd: unsupported operands");
+    GG_REQUIRE(!p.dout || p.w3, "head_bwd: dout needs w3");
     if (p.dcond) head_bwd_k<true><<<(unsigned)((p.rows + 31) / 32), 512, 0, st>>>(p);
     else head_bwd_k<false><<<(unsigned)((p.rows + 31) / 32), 512, 0, st>>>(p);
     GG_CHECK_HIP(hipGetLastError());

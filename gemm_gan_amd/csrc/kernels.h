@@ -13,6 +13,10 @@ struct DropKey {
     // Device word mixed into k0 by every kernel at its start (drop_live): 0 for eagerly enqueued work, the replay number
     // of a captured train step (hipGraph: kernel arguments, hence k0, are frozen at capture) - fresh masks per replay.
     const uint32_t* epoch = nullptr;
+    // Added to k0 AFTER the epoch re-mix: a launch over the row range [r0, M) of a tensor whose stream index is row * ld + col
+    // passes post = (r0 * ld / 2) * DROP_PHI and draws, with LOCAL row indices, the very words the whole-tensor launch draws for
+    // those rows (the pre-mix state is linear in the pair index, drop_rng.h) - drop_key_rows() below.
+    uint32_t post = 0;
 };
 DropKey make_drop_key(float p, uint64_t seed, uint32_t site, uint32_t call);
 
@@ -184,6 +188,8 @@ struct Ffn2P {
     unsigned* stamps = nullptr;                     // tools/ffn2_probe.py: per-phase cycle sums, [workgroups * waves][8]
 };
 bool ffn2_supported(const Ffn2P& p);
+void enc_set_grid(int workgroups);               // tests: cap the persistent grids of enc.hip (0: one workgroup per compute unit)
+long ffn2_sweep_tokens(int variant);            // tokens one pass of the persistent grid covers (workgroup tokens x compute units)
 // variant: 0 = 4-slot weight ring (64 KB), 2 = 8-slot ring (128 KB)
 int ffn2(const Ffn2P& p, hipStream_t st, int variant = 0);
 void ffn2_time_next(hipEvent_t begin, hipEvent_t end);

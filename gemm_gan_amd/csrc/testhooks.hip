@@ -95,6 +95,7 @@ int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1
 // fused feed-forward block of round 4 (enc.hip): the fragment-ordered weight image is built from the fp32 weights into `wfrag`
 // (gg_test_ffn2_frag_bytes() bytes) exactly as refresh_shadows does, then the kernel runs as in cond_forward
 int64_t gg_test_ffn2_frag_bytes(void) { return (int64_t)enc_frag_bytes(1); }
+int gg_test_set_enc_grid(int workgroups) { enc_set_grid(workgroups); return 0; }
 int gg_test_ffn2(const void* X, int64_t M, const float* W1, const float* b1, const float* W2, const float* b2, void* Hs, void* R2, int r2_bf16,
                  int64_t keep_rows, const float* ln_g, const float* ln_b, void* Y, int y_bf16, float* stats, float drop_p, uint64_t drop_seed,
                  uint32_t site1, uint32_t site2, uint32_t drop_call, void* wfrag, int variant, void* stream) {

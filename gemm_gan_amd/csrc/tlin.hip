@@ -1026,7 +1026,7 @@ bool tlin_supported(const TlinP& p) {
 
 // which kernel tlin() launches for p (profiling classes follow the kernels' own names): 0 tlin_str_kernel, 1 tlin_res_kernel
 // (32-token waves), 2 tlin_res16_kernel<..., PRE_RES> (+ residual + LayerNorm), 3 <..., PRE_ACC> (+=), 4 other res16 modes
-static int g_route = 0;                   // tests (gg_test_linear): 1 = keep the token-on-lane kernels
+static thread_local int g_route = 0;      // tests (gg_test_linear, on the calling thread only): 1 = keep the token-on-lane kernels
 void tlin_force_route(int route) { g_route = route; }
 bool wst_routed(const TlinP& p) {
     if (g_route == 1) return false;

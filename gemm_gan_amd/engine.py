@@ -56,6 +56,8 @@ class Engine:
             # The engine's concurrent work (parameter-gradient leaves, generator passes computed ahead) runs on two streams
             # this object owns and binds: kernels on them read the caller's input tensors after an entry point has returned,
             # and the caching allocator orders a block's reuse only against streams the tensor was recorded on (_borrow).
+            # GG_SIDE_PRIO=high: torch's high-priority stream pool (the one ProcessGroupNCCL also draws from); anything else, "low" included,
+            # is the default priority - torch exposes no lower one (the C side's own streams know low|high: engine.hip create_side_stream)
             prio = -1 if os.environ.get("GG_SIDE_PRIO", "") .startswith("h") else 0
             self._side_stream = torch.cuda.Stream(self.device, priority=prio)
             self._pre_stream = torch.cuda.Stream(self.device, priority=prio)

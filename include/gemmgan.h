@@ -285,6 +285,9 @@ int gg_test_ffn_fused(const float* X, int64_t M, const void* W1, const float* b1
 /* fused feed-forward block, round 4 (csrc/enc.hip): X = x1 as bf16 [M,256]; W1 [512,256] / W2 [256,512] fp32 (the fragment-ordered bf16 image is
    built into wfrag, gg_test_ffn2_frag_bytes() bytes); Hs bf16 [M,512], R2 bf16 or fp32 [M,256], stats [M,2] for rows < keep_rows; Y bf16 or fp32 */
 int64_t gg_test_ffn2_frag_bytes(void);
+/* caps the persistent grids of the streamed encoder kernels at `workgroups` (0: one per compute unit, the default): a pass of the grid then
+   covers workgroups * 256 tokens, which lets small test shapes reach the whole-passes + left-over-rows split of the engine's route */
+int gg_test_set_enc_grid(int workgroups);
 int gg_test_ffn2(const void* X, int64_t M, const float* W1, const float* b1, const float* W2, const float* b2, void* Hs, void* R2, int r2_bf16,
                  int64_t keep_rows, const float* ln_g, const float* ln_b, void* Y, int y_bf16, float* stats, float drop_p, uint64_t drop_seed,
                  uint32_t site1, uint32_t site2, uint32_t drop_call, void* wfrag, int variant, void* stream);

@@ -652,13 +652,18 @@ def test_fused_layer_backward_route_matches_the_three_launch_route(dropout, case
     ck.done()
 
 
+@pytest.mark.parametrize("grid", [0, 2])
 @pytest.mark.parametrize("mode", [1, 3])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
-def test_streamed_feed_forward_route_matches_the_two_launch_route(dropout, mode):
+def test_streamed_feed_forward_route_matches_the_two_launch_route(dropout, mode, grid):
     """enc.hip (gg_set_ffn2) inside a critic iteration against FFN1 + FFN2 as two weight-stationary Linears, default bf16 storage
     (bf16 x1 / r2 / x2): same operands and dropout streams; only the bf16 rounding of a hidden value on a tie and the fp32 summation
     order differ.  Every stored row is compared (h / r2 of the forward-only replica are written by neither route... by the
-    two-launch route only for h: compared on the rows both store)."""
+    two-launch route only for h: compared on the rows both store).
+    grid = 2 caps the persistent grid at two workgroups (512 tokens per pass): the 3 * 8 * 65 = 1 560 token rows then split into three
+    whole passes for the streamed kernel and 24 left-over rows for the two Linear launches, as 3 * 256 * 257 rows do on 256 compute
+    units - the left-over rows run the SAME kernels with the SAME dropout words as the all-two-launch route (DropKey::post), so they
+    must come out bit-identical."""
     c = CASES["hot_tiles_E256"]
     cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
     torch.manual_seed(11)
@@ -674,16 +679,26 @@ def test_streamed_feed_forward_route_matches_the_two_launch_route(dropout, mode)
     alpha = torch.rand(B, generator=g).cuda()
     names = ["D.L0.x1", "D.L0.h", "D.L0.x2", "D.L1.x2", "D.c"]
     out = {}
+    lib = L.load()
     for on in (0, mode):
         eng.set_ffn2(on)
+        L.check(lib.gg_test_set_enc_grid(grid if on else 0))
         eng.set_seed(5)
         eng.reset_launch_count()
         eng.critic_backward(x, z, alpha, patches, patch_pad, text, text_pad)
         out[on] = dict(losses=eng.losses.clone(), g=eng.flat[L.ROLE_CRITIC]["g"].clone(), launches=eng.launch_count(),
                        **{n: eng.debug_buffer(n) for n in names})
     eng.set_ffn2(0)
+    L.check(lib.gg_test_set_enc_grid(0))
     a, b = out[mode], out[0]
     assert a["launches"] != b["launches"], (a["launches"], b["launches"])          # the fused kernel really ran (one launch less per layer, one more per shadow refresh)
+    if grid:
+        R0 = 3 if dropout > 0 else 1
+        M0, sweep = R0 * B * (P + 1), grid * 256
+        main = M0 // sweep * sweep
+        assert 0 < main < M0 and (M0 - main) * 8 <= sweep, (M0, main)               # the split is really taken at this shape
+        u, v = a["D.L0.x2"].view(-1, cfg.embedding_dims)[main:M0], b["D.L0.x2"].view(-1, cfg.embedding_dims)[main:M0]
+        assert torch.equal(u, v), "left-over rows of layer 0 differ from the two-launch route (same kernels, same dropout words expected)"
     ck = Checker(f"streamed feed-forward vs two launches, dropout={dropout}, mode={mode}", 6e-3, metric="max")
     R_ = 3 if dropout > 0 else 1
     S_, F_ = P + 1, 2 * cfg.embedding_dims
