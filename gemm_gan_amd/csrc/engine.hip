@@ -132,6 +132,7 @@ struct gg_engine {
     gg_config cfg;
     int E, F, H, G, L, Dt, Dp, nh, nl, dh;
     int maxB, maxP, maxT, maxS, maxR;
+    int preR = 5;              // generator passes one batched prefetch pass holds (prefetch arena / head scratch): GG_PREFETCH_R, 3 .. GG_MAX_PREFETCH
     Net net[2];
     float dropout = 0.f;
     int precision = GG_PREC_F32;
@@ -415,7 +416,7 @@ size_t carve(gg_engine* e, void* base) {
     const long P = e->maxP, Dp = e->Dp;
     carve_cond(e, a, e->actsG, 1);
     carve_cond(e, a, e->actsD, (int)R);
-    carve_cond(e, a, e->actsP, (int)R);
+    carve_cond(e, a, e->actsP, R > 1 ? e->preR : 1);                       // the prefetch arena holds preR dropout replicas (generator_prefetch)
     for (int r = 0; r < 2; ++r) {
         Net& n = e->net[r];
         n.wb = a.take<char>((size_t)n.total * 2);
@@ -431,8 +432,8 @@ size_t carve(gg_engine* e, void* base) {
     }
     e->headG.a1 = a.take<float>(B * H); e->headG.a2 = a.take<float>(B * H); e->headG.out = nullptr;
     e->headD.a1 = a.take<float>(3 * B * H); e->headD.a2 = a.take<float>(3 * B * H); e->headD.out = a.take<float>(3 * B);
-    e->headP.a1 = a.take<float>(3 * B * H); e->headP.a2 = a.take<float>(3 * B * H); e->headP.out = nullptr;
-    e->c3P = a.take<float>(3 * B * E);
+    e->headP.a1 = a.take<float>((long)e->preR * B * H); e->headP.a2 = a.take<float>((long)e->preR * B * H); e->headP.out = nullptr;
+    e->c3P = a.take<float>((long)e->preR * B * E);
     e->X2 = a.take<float>(2 * B * G);
     e->Xpre = a.take<float>((long)GG_MAX_PREFETCH * B * G);
     e->c3 = a.take<float>(3 * B * E);
@@ -1908,6 +1909,23 @@ int generator_prefetch(Ctx& c, const float* z_all, int n, const gg_cond* in, boo
     static const bool pipe_off = getenv("GG_NO_PREFETCH_PIPE") != nullptr;
     bool pipe = !pipe_off && n > 1 && e->side_on && e->flash && e->precision == GG_PREC_BF16 &&
                 (e->x3 ? flash_attn_x3_supported(in->P + 1, e->E, e->nh) : flash_attn_supported(in->P + 1, e->E, e->nh));
+    // Wide form (fused attention path only, as above): ALL passes as dropout replicas of ONE batched pass in the prefetch arena, on the
+    // caller's stream.  A pass costs 0.39 ms + 0.34 ms per replica at cfg3 (FiLM, text and patch encoders and the layer-0 projection run
+    // once per pass, and every launch has its fixed prologue): five replicas at once are 2.1 ms where 1 + 3 + 1 (the pipelined form:
+    // the four later ones sat behind the parameter-gradient launches in the side streams' hardware queue and ran alone anyway,
+    // tools/queue_probe.py) were 2.8 ms and 3 + 2 on one stream 2.45 ms.
+    static const bool wide_off = getenv("GG_NO_PREFETCH_WIDE") != nullptr;
+    const bool wide = !wide_off && n > 1 && e->flash && e->precision == GG_PREC_BF16 &&
+                      (e->x3 ? flash_attn_x3_supported(in->P + 1, e->E, e->nh) : flash_attn_supported(in->P + 1, e->E, e->nh));
+    if (wide) {
+        for (int done = 0; done < n;) {
+            const int r = std::min(n - done, e->preR);
+            GG_TRY(prefetch_chunk(c, z_all, done, r, in, e->actsP, e->headP, e->c3P));
+            done += r;
+        }
+        e->pre_n = n;
+        return 0;
+    }
     // a critic conditioning pass computed ahead lives in the critic's arena: the generator passes take the spare one, in order
     const bool spare = e->dcond_valid;
     if (spare) pipe = false;
@@ -2060,6 +2078,10 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->pe_ln = cfg->variant == GG_VARIANT_IMG;
     e->maxB = cfg->max_batch; e->maxP = cfg->max_patches; e->maxT = cfg->max_text_tokens; e->maxS = e->maxP + 1;
     e->maxR = cfg->dropout > 0.f ? 3 : 1;
+    {
+        const char* pr = getenv("GG_PREFETCH_R");
+        e->preR = std::max(3, std::min(GG_MAX_PREFETCH, pr ? atoi(pr) : 5));
+    }
     e->dropout = cfg->dropout;
     e->seed = cfg->seed;
     GG_REQUIRE(cfg->precision >= GG_PREC_F32 && cfg->precision <= GG_PREC_BF16X3, "bad precision");
