@@ -2347,7 +2347,7 @@ int train_step_body(Ctx& c, const float* x_real, const gg_cond* in, const float*
     const long zs = (long)in->B * e->L;
     static const bool defer = getenv("GG_NO_PREFETCH_DEFER") == nullptr;
     if (n_critic > 1 && e->prefetch_on) GG_TRY(generator_prefetch(c, z_all, n_critic, in, defer));
-    phase_mark(c, "generator: first prefetched pass");
+    phase_mark(c, "generator: passes computed ahead (all of the step in one batched pass)");
     for (int k = 0; k < n_critic; ++k) {
         if (k == 1) GG_TRY(prefetch_rest(e));           // (no-op unless deferred) output 1 is waited for just below
         GG_TRY(critic_backward(c, x_real, z_all + k * zs, alpha_all + (long)k * in->B, in, losses, next_prefetched(c, in->B)));
