@@ -481,6 +481,7 @@ size_t carve(gg_engine* e, void* base) {
 struct Ctx {
     gg_engine* e;
     hipStream_t st;
+    int grid_pct = 0;      // share of the compute units the persistent Linear grids launched through this context take (0: the kernels' default)
 };
 
 inline long tiles_of(long M, long N) { return ((M + 127) / 128) * ((N + 127) / 128); }
@@ -749,7 +750,9 @@ int try_tlin3(Ctx& c, const TlinP& p_in) {
     }
     return tlin3(p, c.st, ns) == 0 ? 1 : -1;
 }
-int try_tlin(Ctx& c, const TlinP& p) {
+int try_tlin(Ctx& c, const TlinP& p_in) {
+    TlinP p = p_in;
+    if (p.grid_pct == 0) p.grid_pct = c.grid_pct;
     if (use_tlin(c.e) && c.e->x3) return try_tlin3(c, p);
     if (!use_tlin(c.e) || !tlin_supported(p)) return 0;
     c.e->launches++;
@@ -1615,6 +1618,10 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
 // ------------------------------------------------------------------------------------------------
 // a1 (+)= cvec @ W1c^T + b1, act ; a2 = act(a1 W2^T + b2) ; out = a2 W3^T + b3
 // `a1` must already hold v @ W1v^T (the non-conditioning part of the first layer).
+inline int fwd_alone_pct() {      // GG_WST_FWD_PCT: grid share of the Linears of a forward pass that runs alone (0: the kernels' default of 91 %)
+    static const int pct = getenv("GG_WST_FWD_PCT") ? atoi(getenv("GG_WST_FWD_PCT")) : 100;
+    return pct;
+}
 int head_finish(Ctx& c, Net& n, const float* cvec, float* a1, float* a2, float* out, long ldo, int rows, int out_rows) {
     gg_engine* e = c.e;
     const int E = e->E, H = e->H;
@@ -1801,7 +1808,13 @@ int critic_head_phase(Ctx& c, const float* x_real, const float* z, const float* 
     {
         const bool have = e->dcond_valid && e->dcond_B == B && e->dcond_P == in->P && e->dcond_T == in->T && e->dcond_R == R;
         e->dcond_valid = false;
-        if (!have) GG_TRY(cond_forward(c, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
+        if (!have) {
+            // nothing runs beside this pass (the previous iteration's parameter-gradient launches were joined before its optimiser
+            // step, the generator passes of the step are done): its persistent Linear grids take every compute unit
+            Ctx cf = c;
+            cf.grid_pct = fwd_alone_pct();
+            GG_TRY(cond_forward(cf, D, in, e->actsD, R, e->dropout, R == 1 ? 1 : 2));
+        }
     }
     phase_mark(c, "critic: conditioning forward (3 replicas)");
     e->crit_R = R;
@@ -1857,7 +1870,11 @@ int prefetch_chunk(Ctx& c, const float* z_all, int first, int r, const gg_cond* 
     Net& Gn = e->net[GG_ROLE_GENERATOR];
     const int B = in->B, G = e->G, E = e->E, H = e->H, Lz = e->L;
     const int rc = e->dropout > 0.f ? r : 1;                                // without dropout the conditioning replicas coincide
-    GG_TRY(cond_forward(c, Gn, in, acts, rc, e->dropout, 0));
+    {
+        Ctx cf = c;
+        if (c.st != e->pre_stream) cf.grid_pct = fwd_alone_pct();       // on the caller's stream, before the critic iterations: alone on the chip
+        GG_TRY(cond_forward(cf, Gn, in, acts, rc, e->dropout, 0));
+    }
     const float* cvec = acts.c;
     if (rc == 1 && r > 1) {
         KL(k_copy_rows_bcast(c3, acts.c, (long)r * B, B, E, c.st));

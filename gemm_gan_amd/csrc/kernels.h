@@ -256,6 +256,7 @@ struct TlinP {
     // fp8 (OCP e4m3) operands: W points at the e4m3 shadow copy (ldw in elements), *w_exp (device) is its per-tensor
     // power-of-two exponent (stored value = w * 2^w_exp), activations are quantised as x * 2^x_exp on load
     int fp8 = 0; const int* w_exp = nullptr; int x_exp = 0;
+    int grid_pct = 0;                               // weight-stationary kernels: share of the compute units the persistent grid takes (0: 91, wst.hip launch())
     int dbg = 0;                                    // timing experiments only (GG_TLIN_DBG): 1 no stores, 2 no MFMA, 4 no weight loads, 8 no X loads
     unsigned long long* stamps = nullptr;           // tools/tlin_probe: 4 s_memtime stamps per workgroup (wave 0)
 };

@@ -537,7 +537,8 @@ int launch(const TlinP& p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     // beside every Linear instead of waiting for one to end (ms per step, interleaved: 100 % 28.96, 97 % 28.94, 94 % 28.66,
     // 91 % 28.61, 88 % 28.82, 75 % 29.45).  GG_WST_CU_PCT overrides.
     static const int cu_pct = getenv("GG_WST_CU_PCT") ? atoi(getenv("GG_WST_CU_PCT")) : 91;
-    const long cus = std::max<long>(8, (long)n_cu * cu_pct / 100 / 8 * 8);
+    // p.grid_pct: the engine asks for the whole chip where it knows nothing runs beside the launch (forward passes on the caller's stream)
+    const long cus = std::max<long>(8, (long)n_cu * (p.grid_pct > 0 ? std::min(p.grid_pct, 100) : cu_pct) / 100 / 8 * 8);
     const long slots = cus * ((NW == 4 && KS < 48) ? 2 : 1);          // resident workgroups: two per CU with 4 waves, one with 8 (or with the K = 768 tile)
     unsigned grid = (unsigned)std::min<long>(ntiles, slots);
     if (GROUPS > 1) {       // owners in whole groups of 8 (one per XCD), GROUPS workgroups each
