@@ -196,7 +196,7 @@ struct gg_engine {
     // whole passes of its persistent grid and leaves the R * B rows past them to the two Linear launches, so WHICH kernel computes a row
     // depends on the row's position in the batch - the two agree to bf16 rounding ties only (6e-3 on activations), and the full-size
     // row-independence / shard-identity properties of tests/test_engine_oracle_gpu.py then hold to 7e-3 instead of 1e-3.  Not worth
-    // 0.19 ms of a 24.9 ms step (profiles/r04_ab_notes.md).
+    // 0.19 ms of a 24.9 ms step (profiles/r04_notes.md).
     int ffn2_on = getenv("GG_FFN2") ? atoi(getenv("GG_FFN2")) : 0;
     int ffn_on = getenv("GG_FFN_FUSED") != nullptr;   // fused feed-forward block (ffn.hip), bf16 mode, E = 256: opt-in (or gg_set_ffn_fused) -
                                // measured 20 % slower than the two launches it replaces (profiles/r03_ffn_fused.md)

@@ -131,3 +131,35 @@ def test_product_path_does_not_import_the_oracle():
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
             assert "oracle" not in re.sub(r"#.*|\"\"\".*?\"\"\"", "", open(os.path.join(pkg, fn)).read(), flags=re.S), fn
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_backward_stage_ranges_tile_the_flat_gradient_buffer_in_reverse_order(name):
+    """gg_cond_stage_range (data-parallel hosts all-reduce a stage's range while the next stage runs): stage 0 ends where the MLP range
+    begins, every later stage ends where the previous one begins, the last one starts at offset 0 - the conditioning part of the flat
+    buffer exactly once, from the back.  The unconditional variant has no stages."""
+    g = Golden(name)
+    lib = L.load()
+    rc, h = _create(g)
+    assert rc == 0, lib.gg_last_error()
+    n_st = lib.gg_cond_stage_count(h)
+    assert n_st == (0 if g.variant == "vanilla" else 2 + 2)
+    off, numel = C.c_int64(), C.c_int64()
+    for role in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+        assert lib.gg_mlp_grad_range(h, role, C.byref(off), C.byref(numel)) == 0
+        last = 0                                                  # end of the last parameter slot (the buffer itself is padded past it)
+        for i in range(lib.gg_param_count(h, role)):
+            po, pn, nd = C.c_int64(), C.c_int64(), C.c_int32()
+            shape = (C.c_int32 * 3)()
+            assert lib.gg_param_info(h, role, i, C.byref(po), C.byref(pn), C.byref(nd), shape) == 0
+            last = max(last, po.value + pn.value)
+        assert last <= off.value + numel.value <= lib.gg_flat_numel(h, role)
+        end = off.value
+        for st in range(n_st):
+            assert lib.gg_cond_stage_range(h, role, st, C.byref(off), C.byref(numel)) == 0
+            # stage 0 (the cross-attention blocks) is empty in the variants without them; hosts skip an empty range
+            assert (numel.value > 0 or (st == 0 and g.variant != "xattn_film")) and off.value + numel.value == end, (role, st, off.value, numel.value, end)
+            end = off.value
+        assert end == 0
+        assert lib.gg_cond_stage_range(h, role, n_st, C.byref(off), C.byref(numel)) != 0          # out of range: an error, not a guess
+    lib.gg_destroy(h)

@@ -163,12 +163,37 @@ def _worker(rank, world, port, q):
         (x, text, text_pad, patches, patch_pad), z_all, alpha_all = batch_and_noise()
         n = B // world
         s = slice(rank * n, (rank + 1) * n)
+        # every gradient all-reduce is logged between the engine calls: which range of which flat buffer, and when
+        flat_ptr = {w.engine.flat[r]["g"].untyped_storage().data_ptr(): r for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC)}
+        real_all_reduce = dist.all_reduce
+
+        def logged_all_reduce(t, *a, **k):
+            r = flat_ptr.get(t.untyped_storage().data_ptr())
+            if r is not None:
+                w.engine.calls.append(("all_reduce", r, t.storage_offset(), t.numel()))
+            return real_all_reduce(t, *a, **k)
+        dist.all_reduce = logged_all_reduce
         w.train_with_noise(x[s], text[s], text_pad[s], patches[s], patch_pad[s], z_all[:, s].contiguous(),
                            alpha_all[:, s].contiguous(), next_cond=(patches[s], patch_pad[s], text[s], text_pad[s]))
-        order = [c[0] for c in w.engine.calls]
-        stages = [str(i) for i in range(CFG.n_layers + 2)]
-        assert order == (["critic_head"] + ["critic_cond" + i for i in stages]) * CFG.n_critic + ["gen_head"] + \
-            ["gen_cond" + i for i in stages] + ["critic_cond_prefetch"], order
+        dist.all_reduce = real_all_reduce
+        n_st = CFG.n_layers + 2
+
+        def iteration(role, head, cond):        # head phase, its MLP bucket, then every backward stage followed at once by ITS range
+            exp = [(head,), ("all_reduce", role) + tuple(w.engine.mlp_range[role])]
+            for i in range(n_st):
+                exp += [(cond + str(i),), ("all_reduce", role) + tuple(w.engine.stage_range[role][i])]
+            return exp
+        seen = [c if c[0] == "all_reduce" else (c[0],) for c in w.engine.calls]
+        expected = iteration(L.ROLE_CRITIC, "critic_head", "critic_cond") * CFG.n_critic + \
+            iteration(L.ROLE_GENERATOR, "gen_head", "gen_cond") + [("critic_cond_prefetch",)]
+        assert seen == expected, (seen, expected)
+        # reverse-layer order: the stage ranges walk the flat buffer from the MLP block down to offset 0, without gaps
+        for r in (L.ROLE_GENERATOR, L.ROLE_CRITIC):
+            end = w.engine.mlp_range[r][0]
+            for off, numel in w.engine.stage_range[r]:
+                assert off + numel == end, (r, off, numel, end)
+                end = off
+            assert end == 0
         sd = {k: v.detach().numpy().copy() for k, v in {**{"g." + k: v for k, v in tr.gen.state_dict().items()},
                                                          **{"d." + k: v for k, v in tr.disc.state_dict().items()}}.items()}
         d_loss_global = float(w.d_batch_loss[0])
