@@ -1,7 +1,11 @@
-"""ctypes binding of libgemmgan.so (C ABI in include/gemmgan.h).
+"""ctypes binding of libgemmgan.so (C ABI in include/gemmgan.h) and of libgemmgan_lab.so (include/gemmgan_lab.h).
 
 The product path has NO fallback: if the HIP library is missing or fails to load, importing the
-engine raises.  ``build()`` compiles it in-tree with hipcc for gfx950 (no GPU needed to build).
+engine raises.  ``build()`` compiles both in-tree with hipcc for gfx950 (no GPU needed to build).
+libgemmgan_lab.so - the kernel-level test hooks and the opt-in kernels that lost their A/B against the default
+routes - is loaded only on demand: by a gg_test_* call through the handle ``load()`` returns, or by ``load_lab()``
+(the Engine's set_ffn2 / set_encb / set_ffn_fused / set_head_fused wrappers, and its constructor when one of the
+GG_FFN2 / GG_ENCB / GG_FFN_FUSED / GG_HEAD_FUSED environment switches is set).
 """
 from __future__ import annotations
 
@@ -11,6 +15,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgemmgan.so")
+LAB_PATH = os.path.join(_HERE, "libgemmgan_lab.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ROLE_GENERATOR, ROLE_CRITIC = 0, 1
@@ -174,11 +179,19 @@ SYMBOLS = {
     "gg_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
 }
 
+SYMBOLS["gg_lab_register"] = (C.c_int, [C.c_void_p, C.c_uint64])
+# include/gemmgan_lab.h: what libgemmgan_lab.so exports
+LAB_SYMBOLS = {k: SYMBOLS.pop(k) for k in list(SYMBOLS) if k.startswith("gg_test_")}
+LAB_SYMBOLS["gg_lab_loaded"] = (C.c_int, [])
+LAB_ENV = ("GG_FFN2", "GG_ENCB", "GG_FFN_FUSED", "GG_HEAD_FUSED")      # environment switches that select kernels of the lab library
+
 _lib = None
+_core = None
+_lab = None
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into gemm_gan_amd/libgemmgan.so for gfx950 (hipcc, in-tree)."""
+    """Compile csrc/*.hip into gemm_gan_amd/libgemmgan.so and libgemmgan_lab.so for gfx950 (hipcc, in-tree)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
     r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
@@ -189,22 +202,59 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _bind(lib, table):
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class _Handle:
+    """What load() returns: attribute access resolves a symbol of include/gemmgan.h in libgemmgan.so, and a symbol of
+    include/gemmgan_lab.h in libgemmgan_lab.so (loaded at that moment if it was not)."""
+
+    def __getattr__(self, name):
+        if name in LAB_SYMBOLS:
+            fn = getattr(load_lab(), name)
+        else:
+            fn = getattr(_core, name)
+        object.__setattr__(self, name, fn)
+        return fn
+
+
 def load():
     """Load the HIP engine.  Raises (never falls back) when the library is absent or broken."""
-    global _lib
+    global _lib, _core
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built "
                           f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`). "
                           "There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _core = _bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL), SYMBOLS)      # global: the lab library resolves its references here
+    _lib = _Handle()
+    return _lib
+
+
+def load_lab():
+    """Load libgemmgan_lab.so (after the engine library); its constructor registers the opt-in kernels with the engine."""
+    global _lab
+    if _lab is not None:
+        return _lab
+    load()
+    if not os.path.exists(LAB_PATH):
+        raise ImportError(f"{LAB_PATH} not found: build it with `make -C {CSRC}` (test hooks and opt-in kernels; the engine "
+                          "itself does not need it)")
+    lab = _bind(C.CDLL(LAB_PATH, mode=C.RTLD_GLOBAL), LAB_SYMBOLS)
+    if lab.gg_lab_loaded() != 1:
+        raise ImportError("libgemmgan_lab.so did not register with libgemmgan.so (libraries of different builds?)")
+    _lab = lab
+    return lab
+
+
+def lab_wanted_by_env() -> bool:
+    return any(k in os.environ for k in LAB_ENV)
 
 
 def check(rc: int):

@@ -20,6 +20,7 @@
 namespace gg {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
+LabTable g_lab;        // entry points of libgemmgan_lab.so, when it is loaded (kernels.h)
 
 namespace {
 constexpr int MAXL = 8;
@@ -675,15 +676,15 @@ int refresh_shadows(Ctx& c, Net& n) {
         return 0;
     }
     KL(k_shadow_weights(n.w, n.wb, n.wtb, n.tab_dev, (int)n.tab.size(), c.st));
-    if (c.e->ffn2_on && !c.e->fp8_fwd && c.e->bstore_on && c.e->xstore_on && c.e->rstore_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {      // cond_forward's streamed-FFN route
+    if (c.e->ffn2_on && g_lab.k_enc_frag_weights && !c.e->fp8_fwd && c.e->bstore_on && c.e->xstore_on && c.e->rstore_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {      // cond_forward's streamed-FFN route
         long o1[MAXL], o2[MAXL];
         for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; }
-        KL(k_enc_frag_weights(n.w, o1, o2, c.e->nl, n.wfrag, c.st));
+        KL(g_lab.k_enc_frag_weights(n.w, o1, o2, c.e->nl, n.wfrag, c.st));
     }
-    if (c.e->encb_on && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {
+    if (c.e->encb_on && g_lab.k_encb_frag_weights && !c.e->no_cond && c.e->E == 256 && c.e->F == 512) {
         long o1[MAXL], o2[MAXL], oo[MAXL];
         for (int l = 0; l < c.e->nl; ++l) { o1[l] = n.layer[l].l1w; o2[l] = n.layer[l].l2w; oo[l] = n.layer[l].sa.ow; }
-        KL(k_encb_frag_weights(n.w, o1, o2, oo, c.e->nl, n.wfragb, c.st));
+        KL(g_lab.k_encb_frag_weights(n.w, o1, o2, oo, c.e->nl, n.wfragb, c.st));
     }
     if (c.e->fp8_fwd) {
         GG_TRY(k_shadow_weights_fp8(n.w, n.w8, n.w8_amax, n.w8_exp, n.tab_dev, (int)n.tab.size(), c.st));
@@ -988,17 +989,17 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             });
         }
         bool ffn_done = false;
-        if (bst && !xst && !e->fp8_fwd && e->ffn_on) {   // x2 = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch: the hidden tile stays on chip
+        if (bst && !xst && !e->fp8_fwd && e->ffn_on && g_lab.ffn_fused) {   // x2 = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)) in one launch: the hidden tile stays on chip
             FfnP f;
             f.X = L.x1; f.M = RB * S; f.E = E; f.F = F;
             f.W1 = WB(n, lp.l1w); f.b1 = w + lp.l1b; f.W2T = WTB(n, lp.l2w); f.b2 = w + lp.l2b;
             f.Hs = L.h; f.R2 = L.r2; f.keep_rows = keep_rows;
             f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b; f.Y = L.x2; f.stats = L.st2;
             f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
-            if (ffn_fused_supported(f)) {
+            if (g_lab.ffn_fused_supported(f)) {
                 const double tokd = (double)RB * S, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
                 ProfScope ps(c, "ffn_fused_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (4.0 * E + 4.0 * E) + kept * (2.0 * F + 4.0 * E) + 4.0 * E * F);
-                KL(ffn_fused(f, c.st));
+                KL(g_lab.ffn_fused(f, c.st));
                 ffn_done = true;
             }
         }
@@ -1042,12 +1043,12 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             }
             return 0;
         };
-        if (!ffn_done && xst && rst && !e->fp8_fwd && e->ffn2_on && E == 256 && F == 512) {   // the streamed form (enc.hip): bf16 x1 in, weights as MFMA fragments through an LDS ring
+        if (!ffn_done && xst && rst && !e->fp8_fwd && e->ffn2_on && g_lab.ffn2 && E == 256 && F == 512) {   // the streamed form (enc.hip): bf16 x1 in, weights as MFMA fragments through an LDS ring
             // The streamed kernel is persistent, one workgroup per compute unit: M = R * B * 257 tokens is a whole number of passes of
             // the grid plus R * B rows (the CLS token), and those rows would cost every launch one more pass on a nearly empty chip
             // (measured: 145 us at 3 * 65 536 rows, 175 us at 3 * 65 792).  It takes the whole passes; the few rows left over go through
             // the two Linear launches (rows are independent in this block).
-            const long Mtot = RB * S, sweep = ffn2_sweep_tokens(e->ffn2_on - 1);
+            const long Mtot = RB * S, sweep = g_lab.ffn2_sweep_tokens(e->ffn2_on - 1);
             long Mmain = Mtot / sweep * sweep;
             if (Mmain == 0 || (Mtot - Mmain) * 8 > sweep) Mmain = Mtot;            // no full pass, or a left-over worth a pass of its own
             Ffn2P f;
@@ -1055,11 +1056,11 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
             f.b1 = w + lp.l1b; f.b2 = w + lp.l2b; f.ln_g = w + lp.n2w; f.ln_b = w + lp.n2b;
             f.Hs = L.h; f.R2 = L.r2; f.r2_bf16 = 1; f.stats = L.st2; f.Y = L.x2; f.y_bf16 = l + 1 < e->nl; f.keep_rows = keep_rows;
             f.drop1 = dkey(e, a, n.role, l, 2); f.drop2 = dkey(e, a, n.role, l, 3);
-            if (ffn2_supported(f) && (f.drop1.p > 0.f) == (f.drop2.p > 0.f)) {
+            if (g_lab.ffn2_supported(f) && (f.drop1.p > 0.f) == (f.drop2.p > 0.f)) {
                 const double tokd = (double)Mmain, kept = keep_rows < 0 ? tokd : std::min<double>(tokd, (double)keep_rows);
                 {
                     ProfScope ps(c, "ffn2_kernel", 2.0 * tokd * 2.0 * E * F, tokd * (2.0 * E + (f.y_bf16 ? 2.0 : 4.0) * E) + kept * (2.0 * F + 2.0 * E + 8.0) + 4.0 * E * F);
-                    KL(ffn2(f, c.st, e->ffn2_on - 1));
+                    KL(g_lab.ffn2(f, c.st, e->ffn2_on - 1));
                 }
                 if (Mmain < Mtot) GG_TRY(ffn_two_launches(Mmain, Mtot - Mmain));
                 ffn_done = true;
@@ -1370,7 +1371,7 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             GG_TRY(side_end(c, fk, 0));
         }
         bool fusedb = false;
-        if (bst && a.xst && a.rst && e->encb_on && e->lnb_on && E == 256 && F == 512 && !e->x3) {
+        if (bst && a.xst && a.rst && e->encb_on && g_lab.enc_bwd && e->lnb_on && E == 256 && F == 512 && !e->x3) {
             // MASK -> dx1 += -> LayerNorm1 backward -> dctx in one streamed launch (enc.hip): dr2 in sdr, dres2 in sdres; dr1 -> dx, dh -> sdh,
             // dres1 -> the second bf16 image of sdres, dctx -> sdctx
             EncBwdP q;
@@ -1379,13 +1380,13 @@ int cond_backward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, const float* d
             q.dh = e->sdh; q.dres1 = reinterpret_cast<__bf16*>(e->sdres) + RB * S * E; q.dctx = e->sdctx;
             q.dg1 = g + lp.n1w; q.db1 = g + lp.n1b; q.dbias1 = g + lp.sa.ob;
             q.drop1 = dkey(e, a, n.role, l, 1); q.gate_scale = ks;
-            if (enc_bwd_supported(q)) {
+            if (g_lab.enc_bwd_supported(q)) {
                 GG_TRY(side_wait(c, 1));
                 GG_TRY(side_wait(c, 4));
                 {
                     const double tokd = (double)RB * S;
                     ProfScope ps(c, "encb_kernel", 2.0 * tokd * (2.0 * E * F + (double)E * E), tokd * (4.0 * E * 2 + 2.0 * E * 4 + 2.0 * F * 2) + 2.0 * (2.0 * E * F + E * E));
-                    KL(enc_bwd(q, c.st));
+                    KL(g_lab.enc_bwd(q, c.st));
                 }
                 fusedb = true;
                 Ctx cs = c;
@@ -1627,15 +1628,15 @@ int head_finish(Ctx& c, Net& n, const float* cvec, float* a1, float* a2, float* 
     const int E = e->E, H = e->H;
     const float* w = n.w;
     const float slope = e->cfg.negative_slope;
-    if (e->head_on && e->precision == GG_PREC_BF16 && !e->x3) {       // the chain in one launch (head.hip); the generator's wide output layer stays a GEMM
+    if (e->head_on && g_lab.head_fwd && e->precision == GG_PREC_BF16 && !e->x3) {       // the chain in one launch (head.hip); the generator's wide output layer stays a GEMM
         HeadP h;
         h.rows = rows; h.H = H; h.E = E; h.slope = slope;
         h.W1c = w + n.w1 + n.V; h.ldw1 = n.V + E; h.b1 = w + n.b1; h.W2 = w + n.w2; h.b2 = w + n.b2;
         h.cvec = cvec; h.a1 = a1; h.a2 = a2;
         const bool score = out && out_rows > 0 && n.OUT == 1;
         if (score) { h.w3 = w + n.w3; h.b3 = w + n.b3; h.out = out; h.ldo = ldo; h.out_rows = out_rows; }
-        if (head_fused_supported(h)) {
-            KL(head_fwd(h, c.st));
+        if (g_lab.head_fused_supported(h)) {
+            KL(g_lab.head_fwd(h, c.st));
             if (out && out_rows > 0 && !score) GG_TRY(lin_fwd(c, a2, H, w + n.w3, H, w + n.b3, out, ldo, out_rows, n.OUT, H));
             return 0;
         }
@@ -1668,15 +1669,15 @@ int head_backward(Ctx& c, Net& n, const float* dout, const float* vin, const flo
         GG_TRY(side_end(c, fk, 3));
     }
     bool fused = false;
-    if (e->head_on && e->precision == GG_PREC_BF16 && !e->x3) {      // dh2, dh1 (and dcond) in one launch (head.hip)
+    if (e->head_on && g_lab.head_bwd && e->precision == GG_PREC_BF16 && !e->x3) {      // dh2, dh1 (and dcond) in one launch (head.hip)
         HeadP h;
         h.rows = rows; h.H = H; h.E = E; h.slope = slope;
         h.W1c = w + n.w1 + V; h.ldw1 = V + E; h.W2 = w + n.w2; h.w3 = w + n.w3;
         h.a1 = const_cast<float*>(a1); h.a2 = const_cast<float*>(a2); h.dh2 = dh2; h.dh1 = dh1; h.dcond = dcond;
-        if (head_fused_supported(h)) {
+        if (g_lab.head_fused_supported(h)) {
             if (OUT == 1) h.dout = dout;
             else GG_TRY(lin_bwd_data(c, dout, OUT, w + n.w3, H, dh2, H, rows, OUT, H));       // the generator's wide layer: dh2 <- dout W3
-            KL(head_bwd(h, c.st));
+            KL(g_lab.head_bwd(h, c.st));
             fused = true;
         }
     }
@@ -2073,6 +2074,12 @@ extern "C" {
 const char* gg_last_error(void) { return gg::g_err.c_str(); }
 const char* gg_version(void) { return "gemm_gan_amd 0.3 (gfx950: bf16-MFMA engine, bf16x3 split-operand and f32-MFMA parity modes)"; }
 
+// libgemmgan_lab.so hands over its entry points when it is loaded (include/gemmgan_lab.h); `bytes` guards against a stale build
+int gg_lab_register(const void* table, uint64_t bytes) {
+    GG_REQUIRE(table && bytes == sizeof(LabTable), "gg_lab_register: table of another build");
+    g_lab = *static_cast<const LabTable*>(table);
+    return 0;
+}
 int gg_create(const gg_config* cfg, gg_engine** out) {
     GG_REQUIRE(cfg && out, "null argument");
     GG_REQUIRE(cfg->n_heads > 0 && cfg->embedding_dims % cfg->n_heads == 0, "embedding_dims must divide by n_heads");
@@ -2087,6 +2094,8 @@ int gg_create(const gg_config* cfg, gg_engine** out) {
     e->E = cfg->embedding_dims; e->F = 2 * e->E; e->H = cfg->hidden_dims; e->G = cfg->n_genes; e->L = cfg->latent_dims;
     e->Dt = cfg->text_dims; e->Dp = cfg->patch_dims; e->nh = cfg->n_heads; e->nl = cfg->n_layers; e->dh = e->E / e->nh;
     GG_REQUIRE(cfg->variant >= GG_VARIANT_XATTN_FILM && cfg->variant <= GG_VARIANT_VANILLA, "unknown variant");
+    GG_REQUIRE((!e->ffn2_on || g_lab.ffn2) && (!e->encb_on || g_lab.enc_bwd) && (!e->ffn_on || g_lab.ffn_fused) && (!e->head_on || g_lab.head_fwd),
+               "GG_FFN2 / GG_ENCB / GG_FFN_FUSED / GG_HEAD_FUSED select kernels of libgemmgan_lab.so, which is not loaded");
     e->no_cond = cfg->variant == GG_VARIANT_VANILLA;
     GG_REQUIRE(!e->no_cond || cfg->dropout == 0.f, "the unconditional variant has no dropout site");
     e->xattn = cfg->variant == GG_VARIANT_XATTN_FILM;
@@ -2535,6 +2544,7 @@ int gg_set_flash(gg_engine* e, int on) {
 }
 int gg_set_encb(gg_engine* e, int on) {
     GG_REQUIRE(e, "null engine");
+    GG_REQUIRE(!on || g_lab.enc_bwd, "gg_set_encb: this kernel lives in libgemmgan_lab.so, which is not loaded");
     e->encb_on = on != 0;
     drop_graphs(e);
     return 0;
@@ -2542,12 +2552,14 @@ int gg_set_encb(gg_engine* e, int on) {
 int gg_set_ffn2(gg_engine* e, int mode) {
     GG_REQUIRE(e, "null engine");
     GG_REQUIRE(mode == 0 || mode == 1 || mode == 3, "gg_set_ffn2: 0 off, 1 / 3 on (4- / 8-slot weight ring)");
+    GG_REQUIRE(mode == 0 || g_lab.ffn2, "gg_set_ffn2: this kernel lives in libgemmgan_lab.so, which is not loaded");
     e->ffn2_on = mode;
     drop_graphs(e);
     return 0;
 }
 int gg_set_ffn_fused(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
+    GG_REQUIRE(!on || g_lab.ffn_fused, "gg_set_ffn_fused: this kernel lives in libgemmgan_lab.so, which is not loaded");
     e->ffn_on = on != 0;
     return 0;
 }
@@ -2568,6 +2580,7 @@ int gg_set_bstore(gg_engine* e, int on) {
 }
 int gg_set_head_fused(gg_engine* e, int on) {
     GG_REQUIRE(e, "null argument");
+    GG_REQUIRE(!on || g_lab.head_fwd, "gg_set_head_fused: this kernel lives in libgemmgan_lab.so, which is not loaded");
     e->head_on = on != 0;
     return 0;
 }
@@ -2784,46 +2797,6 @@ int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel) 
     }
     set_error("unknown debug buffer '" + s + "'");
     return -3;
-}
-
-int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                 int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
-                 void* stream) {
-    GemmP p;
-    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
-    p.accumulate = accumulate;
-    return gemm_f32(p, (hipStream_t)stream);
-}
-
-
-int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                       int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
-                       void* stream) {
-    GemmP p;
-    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
-    p.accumulate = accumulate;
-    return gemm_small(p, (hipStream_t)stream);
-}
-
-/* K-strided operands stored as bf16 (the weight-gradient products of bf16-stored branch gradients / activations) */
-int gg_test_gemm_bf16_stored(const void* A, const void* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                             int a_bf16, int b_bf16, int splitk, void* stream) {
-    GemmP p;
-    p.A = reinterpret_cast<const float*>(A); p.B = reinterpret_cast<const float*>(B); p.C = C; p.M = M; p.N = N; p.K = K;
-    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = a_bf16; p.b_bf16 = b_bf16; p.splitk = splitk;
-    return gemm_bf16(p, (hipStream_t)stream);
-}
-
-int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                      int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
-                      void* stream) {
-    GemmP p;
-    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
-    p.accumulate = accumulate;
-    return gemm_bf16(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -193,7 +193,7 @@ long ffn2_sweep_tokens(int variant);            // tokens one pass of the persis
 // variant: 0 = 4-slot weight ring (64 KB), 2 = 8-slot ring (128 KB)
 int ffn2(const Ffn2P& p, hipStream_t st, int variant = 0);
 void ffn2_time_next(hipEvent_t begin, hipEvent_t end);
-size_t enc_frag_bytes(int nl);                      // bytes of the fragment-ordered image of nl layers
+inline size_t enc_frag_bytes(int nl) { return (size_t)nl * 32 * 16384; }      // bytes of the fragment-ordered image of nl layers: 32 ring slots of 16 KB each (enc.hip FFN_SLOTS, SLOT)
 // out[layer] = fragment stream of linear1.weight [512][256] at w + w1_off[layer] and linear2.weight [256][512] at w + w2_off[layer]
 int k_enc_frag_weights(const float* w, const long* w1_off, const long* w2_off, int nl, void* out, hipStream_t st);
 
@@ -214,7 +214,7 @@ struct EncBwdP {
 };
 bool enc_bwd_supported(const EncBwdP& p);
 int enc_bwd(const EncBwdP& p, hipStream_t st);
-size_t encb_frag_bytes(int nl);
+inline size_t encb_frag_bytes(int nl) { return (size_t)nl * 40 * 16384; }     // 40 slots per layer (enc.hip BWD_SLOTS)
 // out[layer] = backward fragment stream of linear2.weight [256][512] (as W2^T), linear1.weight [512][256] (as W1^T) and out_proj.weight [256][256] (as Wo^T)
 int k_encb_frag_weights(const float* w, const long* w1_off, const long* w2_off, const long* wo_off, int nl, void* out, hipStream_t st);
 
@@ -352,4 +352,25 @@ int k_opt_step(float* w, const float* g, float* s1, float* s2, long n, int kind,
                const float* partials, int n_partials, float grad_scale, int step_t, const uint32_t* t_off, hipStream_t st);
 // (t_off: optional device word added to step_t for the Adam bias corrections, which are computed on the device)
 
+
+// ---- opt-in kernels outside the product library ---------------------------------------------------------------------------------
+// The kernels that were built, tested and LOST their A/B against the default routes (ffn.hip, enc.hip, head.hip)
+// live in libgemmgan_lab.so together with the kernel-level test hooks.  Loading that library registers its entry points here
+// (gg_lab_register, include/gemmgan_lab.h); the engine's opt-in routes run only when the pointer is set, and the switches that
+// select them (gg_set_ffn2, gg_set_encb, gg_set_ffn_fused, gg_set_head_fused, the GG_* environment forms) fail loudly when it is not.
+struct LabTable {
+    bool (*ffn_fused_supported)(const FfnP&) = nullptr;
+    int (*ffn_fused)(const FfnP&, hipStream_t) = nullptr;
+    bool (*ffn2_supported)(const Ffn2P&) = nullptr;
+    int (*ffn2)(const Ffn2P&, hipStream_t, int) = nullptr;
+    long (*ffn2_sweep_tokens)(int) = nullptr;
+    int (*k_enc_frag_weights)(const float*, const long*, const long*, int, void*, hipStream_t) = nullptr;
+    bool (*enc_bwd_supported)(const EncBwdP&) = nullptr;
+    int (*enc_bwd)(const EncBwdP&, hipStream_t) = nullptr;
+    int (*k_encb_frag_weights)(const float*, const long*, const long*, const long*, int, void*, hipStream_t) = nullptr;
+    bool (*head_fused_supported)(const HeadP&) = nullptr;
+    int (*head_fwd)(const HeadP&, hipStream_t) = nullptr;
+    int (*head_bwd)(const HeadP&, hipStream_t) = nullptr;
+};
+extern LabTable g_lab;          // engine.hip
 }  // namespace gg

@@ -1,10 +1,10 @@
-// Kernel-level test entry points (tests/ only; declared in include/gemmgan.h under "test hooks").
+// Kernel-level test entry points (tests/ and tools/ only; declared in include/gemmgan_lab.h; built into libgemmgan_lab.so).
 //
 // Each hook launches ONE kernel family of the hot path exactly as engine.hip does - same host wrappers, same routing
 // (weight-stationary -> token-on-lane Linear, resident -> streaming attention) - on buffers the test supplies, so that
 // tests/test_kernels_gpu.py can compare the kernels the bench times against a float64 product of host-rounded
 // operands, dropout included (the mask is regenerated on the host from the (seed, site, call) triple: drop_rng.h).
-#include "../../include/gemmgan.h"
+#include "../../include/gemmgan_lab.h"
 #include "gg_common.h"
 #include "kernels.h"
 
@@ -187,6 +187,46 @@ int gg_test_ln_bwd(const float* dy, const float* r, const float* stats, const fl
     GG_REQUIRE(dy && r && stats && g && dr && dgamma && dbeta, "null argument");
     return k_layernorm_bwd(dy, r, stats, g, dr, dres_out, dgamma, dbeta, dbias, rows, E,
                            make_drop_key(drop_p, drop_seed, drop_site, drop_call), (hipStream_t)stream, dres_bf16);
+}
+
+int gg_test_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                 int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                 void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_f32(p, (hipStream_t)stream);
+}
+
+
+int gg_test_gemm_small(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                       int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                       void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_small(p, (hipStream_t)stream);
+}
+
+/* K-strided operands stored as bf16 (the weight-gradient products of bf16-stored branch gradients / activations) */
+int gg_test_gemm_bf16_stored(const void* A, const void* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                             int a_bf16, int b_bf16, int splitk, void* stream) {
+    GemmP p;
+    p.A = reinterpret_cast<const float*>(A); p.B = reinterpret_cast<const float*>(B); p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.layA = LAY_KS; p.layB = LAY_KS; p.a_bf16 = a_bf16; p.b_bf16 = b_bf16; p.splitk = splitk;
+    return gemm_bf16(p, (hipStream_t)stream);
+}
+
+int gg_test_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                      int layA, int layB, int splitk, float alpha, const float* bias, int act, float slope, int accumulate,
+                      void* stream) {
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.layA = layA; p.layB = layB; p.splitk = splitk; p.alpha = alpha; p.bias = bias; p.act = act; p.slope = slope;
+    p.accumulate = accumulate;
+    return gemm_bf16(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

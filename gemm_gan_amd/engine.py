@@ -31,6 +31,8 @@ class Engine:
                  optimizer="rms_prop", gp_weight=10.0, clip_d=10.0, clip_g=2.0, max_batch=8, max_patches=256,
                  max_text_tokens=1, seed=0, device="cuda:0", precision="bf16x3", variant="xattn_film"):
         self.lib = L.load()
+        if L.lab_wanted_by_env():        # an environment switch selects a kernel of libgemmgan_lab.so: register it before gg_create
+            L.load_lab()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("gemm_gan_amd needs a ROCm GPU (cuda:N device); there is no CPU fallback")
@@ -315,6 +317,9 @@ class Engine:
         L.check(self.lib.gg_set_sqx(self.h, int(on)))
 
     def set_head_fused(self, on: bool):
+        """Fused MLP-head chain (csrc/head.hip, libgemmgan_lab.so: loaded here when switched on)."""
+        if on:
+            L.load_lab()
         L.check(self.lib.gg_set_head_fused(self.h, int(on)))
 
     def set_lnb_fused(self, on: bool):
@@ -337,14 +342,21 @@ class Engine:
         return out
 
     def set_encb(self, on: bool):
-        """Fused backward of the token-local chain of an encoder layer (csrc/enc.hip encb_kernel)."""
+        """Fused backward of the token-local chain of an encoder layer (csrc/enc.hip encb_kernel, libgemmgan_lab.so)."""
+        if on:
+            L.load_lab()
         L.check(self.lib.gg_set_encb(self.h, int(on)))
 
     def set_ffn2(self, mode: int):
-        """Streamed fused feed-forward block (csrc/enc.hip): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring)."""
+        """Streamed fused feed-forward block (csrc/enc.hip, libgemmgan_lab.so): 0 off, 1 on (4-slot weight ring), 3 on (8-slot ring)."""
+        if mode:
+            L.load_lab()
         L.check(self.lib.gg_set_ffn2(self.h, int(mode)))
 
     def set_ffn_fused(self, on: bool):
+        """Fused feed-forward block of round 3 (csrc/ffn.hip, libgemmgan_lab.so)."""
+        if on:
+            L.load_lab()
         L.check(self.lib.gg_set_ffn_fused(self.h, int(on)))
 
     def set_tlin(self, on: bool):

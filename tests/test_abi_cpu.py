@@ -1,5 +1,5 @@
-"""CPU-side checks of the C-ABI boundary: the library loads without a GPU, exports every symbol
-include/gemmgan.h declares, and its parameter layout is the reference's live state_dict."""
+"""CPU-side checks of the C-ABI boundary: the libraries load without a GPU, export every symbol
+include/gemmgan.h / include/gemmgan_lab.h declare, and the parameter layout is the reference's live state_dict."""
 import ctypes as C
 import os
 import re
@@ -14,8 +14,8 @@ from gemm_gan_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "gemmgan.h")).read()
+def _header_symbols(header="gemmgan.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(gg_[a-z_0-9]+)\s*\(", src)))
 
@@ -24,10 +24,56 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = L.load()
     names = _header_symbols()
     assert len(names) >= 25
+    core = C.CDLL(L.LIB_PATH)
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in gemmgan.h but not exported"
-    assert set(names) == set(L.SYMBOLS), "ctypes table and header disagree"
+        assert hasattr(core, n), f"{n} declared in gemmgan.h but not exported by libgemmgan.so"
+    assert set(names) | {"gg_lab_register"} == set(L.SYMBOLS), "ctypes table and header disagree"
+    assert not [n for n in names if n.startswith("gg_test_")], "test hooks belong to gemmgan_lab.h / libgemmgan_lab.so"
     assert b"gfx950" in lib.gg_version()
+
+
+def test_lab_library_loads_registers_and_exports_every_declared_symbol():
+    """include/gemmgan_lab.h: gg_lab_register is the product library's, everything else libgemmgan_lab.so's; loading the lab
+    library registers its opt-in kernels (gg_lab_loaded() == 1) - without a GPU."""
+    names = [n for n in _header_symbols("gemmgan_lab.h")]
+    assert "gg_lab_register" in names and hasattr(C.CDLL(L.LIB_PATH), "gg_lab_register")
+    lab = L.load_lab()
+    assert lab.gg_lab_loaded() == 1
+    lab_names = [n for n in names if n != "gg_lab_register"]
+    for n in lab_names:
+        assert hasattr(lab, n), f"{n} declared in gemmgan_lab.h but not exported by libgemmgan_lab.so"
+    assert set(lab_names) == set(L.LAB_SYMBOLS), "ctypes table and header disagree"
+    core = C.CDLL(L.LIB_PATH)
+    assert not [n for n in lab_names if hasattr(core, n)], "a test hook is still exported by the product library"
+
+
+def test_opt_in_kernel_switches_fail_loudly_without_the_lab_library():
+    """In a process that has not loaded libgemmgan_lab.so the switches of its kernels return an error (no silent fallback to the
+    default route): checked in a child process, this one has the library loaded by other tests."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from gemm_gan_amd import _lib as L\n"
+        "lib = L.load()\n"
+        "vals = dict(n_genes=64, latent_dims=16, embedding_dims=32, hidden_dims=24, text_dims=16, patch_dims=16, n_heads=4, n_layers=2,\n"
+        "            negative_slope=0.01, dropout=0.0, lr_d=5e-4, lr_g=5e-4, optimizer=0, gp_weight=10.0, clip_d=10.0, clip_g=2.0,\n"
+        "            max_batch=4, max_patches=8, max_text_tokens=1, seed=0, precision=1, variant=0)\n"
+        "cfg = L.GGConfig(*[vals[f[0]] for f in L.GGConfig._fields_])\n"
+        "h = C.c_void_p()\n"
+        "assert lib.gg_create(C.byref(cfg), C.byref(h)) == 0\n"
+        "for fn, arg in ((lib.gg_set_ffn2, 1), (lib.gg_set_encb, 1), (lib.gg_set_ffn_fused, 1), (lib.gg_set_head_fused, 1)):\n"
+        "    assert fn(h, arg) != 0 and b'libgemmgan_lab.so' in lib.gg_last_error()\n"
+        "    assert fn(h, 0) == 0\n"
+        "print('ok')\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in L.LAB_ENV}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+    env["GG_FFN2"] = "1"          # the environment form: gg_create itself refuses
+    code2 = code.replace("assert lib.gg_create(C.byref(cfg), C.byref(h)) == 0", "assert lib.gg_create(C.byref(cfg), C.byref(h)) != 0 and b'libgemmgan_lab.so' in lib.gg_last_error(); print('ok'); sys.exit(0)")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
 def _create(g: Golden, **over):
