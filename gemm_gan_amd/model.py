@@ -517,10 +517,12 @@ class WGAN_GP:
         # same torch RNG draws, in the same order, as the reference loop (z, alpha) x n_critic, then z (R:472-476)
         z_all = torch.empty(n + 1, B, self.latent_dims, device=dev)
         alpha_all = torch.empty(n, B, device=dev)
+        # (drawn straight into their slots: `out=` takes the same draws from the generator as the reference's allocating calls - one
+        # kernel per draw instead of a draw and a copy)
         for k in range(n):
-            z_all[k] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev, generator=gen)
-            alpha_all[k] = torch.rand(B, 1, device=dev, generator=gen).view(B)
-        z_all[n] = torch.normal(0, 1, size=(B, self.latent_dims), device=dev, generator=gen)
+            torch.normal(0, 1, size=(B, self.latent_dims), generator=gen, out=z_all[k])
+            torch.rand(B, 1, generator=gen, out=alpha_all[k].view(B, 1))
+        torch.normal(0, 1, size=(B, self.latent_dims), generator=gen, out=z_all[n])
         next_cond = None
         if next_batch is not None and self._world() > 1:
             _, ntext, ntpad, npat, nppad = self._prep(*next_batch)

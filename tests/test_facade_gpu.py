@@ -149,3 +149,24 @@ def test_generate_samples_all_and_dumps(tmp_path):
                                                     "train_primary_site_real", "train_primary_site_gen",
                                                     "test_primary_site_real", "test_primary_site_gen"))
         assert np.load(dd / "data_gen.npy").shape == (d["B"], d["G"]) and np.array_equal(np.load(dd / "test_real.npy"), x.numpy())
+
+
+def test_train_draws_the_reference_noise_stream():
+    """train() (R:463-477) draws (z, alpha) x n_critic and then z with torch.normal / torch.rand in the reference's order from the
+    default generator; the facade draws them straight into their slots (`out=`), which must leave the stream unchanged."""
+    g = Golden(XATTN_FIXTURES[0])
+    d = g.dims
+    w = build(g)
+    x, text, text_pad, patches, patch_pad = g.inputs()
+    B = x.shape[0]
+    seen = {}
+    w.train_with_noise = lambda x, text, tpad, pat, ppad, z_all, alpha_all, **k: seen.update(z=z_all.clone(), a=alpha_all.clone())
+    dev = torch.device("cuda:0")
+    torch.manual_seed(77)
+    w.train(x, text, text_pad, patches, patch_pad)
+    torch.manual_seed(77)
+    for k in range(d["n_critic"]):
+        z = torch.normal(0, 1, size=(B, d["L"]), device=dev)                 # R:473
+        a = torch.rand(B, 1, device=dev)                                    # R:354
+        assert torch.equal(seen["z"][k], z) and torch.equal(seen["a"][k], a.view(B)), k
+    assert torch.equal(seen["z"][d["n_critic"]], torch.normal(0, 1, size=(B, d["L"]), device=dev))      # R:476
