@@ -171,6 +171,12 @@ def pmc_step_bytes(args):
     return None, None
 
 
+def rccl_options():
+    """gemm_gan_amd.rccl_process_group_options(): RCCL's internal stream from torch's high-priority pool (GG_RCCL_DEFAULT_PRIO=1: the default, A/B)."""
+    from gemm_gan_amd.model import rccl_process_group_options
+    return None if os.environ.get("GG_RCCL_DEFAULT_PRIO") == "1" else rccl_process_group_options()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -263,9 +269,16 @@ def main():
         # data-parallel path on a single-GPU box (never used for reported numbers).
         backend = os.environ.get("GG_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, pg_options=rccl_options())
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("GG_FORCE_DP_COLLECTIVES") == "1":
+        # ONE rank, real RCCL: the data-parallel host loop with every all-reduce it issues on N ranks (5 per optimiser step, from the side
+        # stream, under the backward stages) - what the loop and RCCL's launch path cost a step on a one-GPU box; not a scaling number
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ["GG_FORCE_DP_LOOP"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=rccl_options())
 
     import gemm_gan_amd as gga
     G, B, P, T = args.genes, args.batch, args.patches, args.tokens
@@ -298,7 +311,8 @@ def main():
         patch_pad[: int(round(B * args.pad_frac)), P - P // 4:] = True
     text_pad = torch.zeros(B, T, dtype=torch.bool, device=dev)
 
-    w.measure_comm = world > 1
+    forced_coll = world == 1 and dist.is_initialized()       # GG_FORCE_DP_COLLECTIVES: the N-rank host loop with its collectives on one rank
+    w.measure_comm = world > 1 or forced_coll
 
     def train_once():
         if vanilla:
@@ -309,7 +323,7 @@ def main():
             # data parallel: the next step's conditioning inputs are known (here: the same synthetic shard), so the critic's
             # first conditioning forward of the next step runs under this step's generator all-reduce
             w.train(x, text, text_pad, patches, patch_pad,
-                    next_batch=(x, text, text_pad, patches, patch_pad) if world > 1 else None)
+                    next_batch=(x, text, text_pad, patches, patch_pad) if (world > 1 or forced_coll) else None)
 
     def sync():
         if world > 1:
@@ -335,7 +349,7 @@ def main():
             w.engine.profile(False)
             w.engine.set_side_streams(True)
     sync()
-    if world > 1:
+    if world > 1 or forced_coll:
         w.comm_wait_ms()                          # drop the warm-up's event pairs
     if prof:
         # The timed region carries event pairs for the DOMINANT family and the side-stream family only (live roofline over the
@@ -380,7 +394,7 @@ def main():
                           "untimed step after the timed region, summed per phase kind over the 5 critic iterations + the generator "
                           "iteration; a phase's time includes waiting for side-stream work it joins"}
     graph_stats = w.engine.graph_stats() if w.engine.graph else None
-    comm_ms = w.comm_wait_ms() / args.steps if world > 1 else 0.0
+    comm_ms = w.comm_wait_ms() / args.steps if (world > 1 or forced_coll) else 0.0
     t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -438,7 +452,7 @@ def main():
                                       + (f", {args.pad_frac:.0%} of samples with the last {P // 4} patches padded" if args.pad_frac > 0 else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}", "kernel_launches_per_step": launches_per_step,
                           "hip_graph": graph_stats,
-                          "allreduce_wait_ms_per_step": round(comm_ms, 3) if world > 1 else None},
+                          "allreduce_wait_ms_per_step": round(comm_ms, 3) if (world > 1 or forced_coll) else None},
                "finite": finite,
                "losses": {"d": losses_head[0], "g": losses_head[1]}}
         if parity is not None:
@@ -553,7 +567,7 @@ def main():
             out["roofline"]["step"] = step
         else:
             out["roofline_step"] = step
-        if world > 1:
+        if world > 1 or forced_coll:
             out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                                            "buckets_per_optimizer_step": 1 if vanilla else 1 + getattr(w.engine, "cond_stages", 0),
                                            "optimizer_steps_per_train": 6,
@@ -563,7 +577,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 
