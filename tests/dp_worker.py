@@ -67,7 +67,9 @@ def main():
     if backend == "nccl":
         device = f"cuda:{rank}"
         torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        import gemm_gan_amd as gga
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device),
+                                pg_options=gga.rccl_process_group_options())        # as INTEGRATION.md section 3 prescribes
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)          # before anything touches the GPU
     try:
