@@ -2752,8 +2752,8 @@ int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel) 
     std::string s(name);
     auto ret = [&](void* p, long n) { *ptr = p; *numel = n; return 0; };
     const long E = e->E, F = e->F, H = e->H, G = e->G, nh = e->nh, Dp = e->Dp;
-    if (s.size() > 2 && s[1] == '.' && (s[0] == 'G' || s[0] == 'D')) {
-        CondActs& a = s[0] == 'G' ? e->actsG : e->actsD;
+    if (s.size() > 2 && s[1] == '.' && (s[0] == 'G' || s[0] == 'D' || s[0] == 'P')) {      // P: the arena of the generator passes computed ahead
+        CondActs& a = s[0] == 'G' ? e->actsG : (s[0] == 'D' ? e->actsD : e->actsP);
         const long B = a.B, RB = (long)a.R * a.B, S = a.P + 1, T = a.T;
         std::string f = s.substr(2);
         if (f == "gbpre") return ret(a.gbpre, B * 2 * Dp);
@@ -2793,6 +2793,7 @@ int gg_debug_buffer(gg_engine* e, const char* name, void** ptr, int64_t* numel) 
         if (s == "gp_coef") return ret(e->gp_coef, B);
         if (s == "dc") return ret(e->dc, 2 * B * E);
         if (s == "dxfake") return ret(e->dxfake, B * G);
+        if (s == "Xpre") return ret(e->Xpre, (long)e->pre_n * e->pre_B * G);          // generator outputs computed ahead, [n, B, G]
         if (s == "sPd") return ret(e->sPd, (long)e->actsD.R * B * nh * (e->actsD.P + 1) * (e->actsD.P + 1));
     }
     set_error("unknown debug buffer '" + s + "'");

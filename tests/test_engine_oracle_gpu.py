@@ -835,6 +835,46 @@ def test_generator_prefetch_equals_sequential_passes():
     ck.done()
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_batched_generator_pass_of_five_replicas(prec):
+    """With dropout on, the n_critic generator passes of a step run as dropout replicas of ONE batched pass in the prefetch arena
+    (R = 5; the dropout-free case above shares one conditioning pass and never stacks replicas).  (1) A drop probability of 1e-7 keeps
+    every element (threshold round(p * 65536) = 0): the five stacked conditioning vectors and outputs must then equal five one-replica
+    generator forwards with the same z - the R = 5 arithmetic against R = 1.  (2) At p = 0.1 the replicas draw independent masks:
+    their conditioning vectors differ pairwise, everything stays finite."""
+    c = CASES["hot_tiles_E256"]
+    cfg, B, P, T = c["cfg"], c["B"], c["P"], c["T"]
+    torch.manual_seed(11)
+    tr = Trainer(cfg)
+    x, text, text_pad, patches, patch_pad = dev(*synthetic_batch(cfg, B, P, T, seed=12, pad_patches=True, pad_text=True))
+    n = 5
+    z_all = torch.randn(n, B, cfg.latent_dims, generator=torch.Generator().manual_seed(7)).cuda()
+    eng = engine_from_cfg(cfg, B, P, T, dropout=0.1, seed=5)
+    load_oracle_state(eng, tr)
+    eng.set_precision(prec)
+    eng.set_dropout(1e-7)
+    eng.generator_prefetch(z_all.contiguous(), patches, patch_pad, text, text_pad)
+    torch.cuda.synchronize()
+    cP = eng.debug_buffer("P.c").view(n, B, -1).clone()
+    xP = eng.debug_buffer("Xpre").view(n, B, -1).clone()
+    tol = 1e-3 if prec == "bf16x3" else 2e-2                     # bf16: rounding ties of stored activations between the R = 5 and R = 1 kernels' tilings
+    ck = Checker(f"batched generator pass, 5 replicas, all-keep dropout ({prec})", tol, metric="max")
+    for k in range(n):
+        xk = eng.forward(L.ROLE_GENERATOR, z_all[k].contiguous(), patches, patch_pad, text, text_pad, train=True)
+        ck.check(f"pass {k}: generated genes", xP[k], xk)
+        ck.check(f"pass {k}: conditioning vector", cP[k], eng.debug_buffer("G.c").view(B, -1))
+    ck.done()
+    eng.set_dropout(0.1)
+    eng.set_seed(5)
+    eng.generator_prefetch(z_all.contiguous(), patches, patch_pad, text, text_pad)
+    torch.cuda.synchronize()
+    cP = eng.debug_buffer("P.c").view(n, B, -1)
+    assert torch.isfinite(cP).all() and torch.isfinite(eng.debug_buffer("Xpre")).all()
+    for a in range(n):
+        for b in range(a + 1, n):
+            assert (cP[a] - cP[b]).abs().max() > 1e-4, (a, b)              # independent draws per replica
+
+
 @pytest.mark.parametrize("case", ["hot_tiles_E256", "cls_tail_S257"])
 def test_side_streams_do_not_change_results(case):
     """The engine's side streams (parameter-gradient leaves beside the data-gradient chain, the generator iteration's two
