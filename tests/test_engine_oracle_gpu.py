@@ -857,7 +857,7 @@ def test_batched_generator_pass_of_five_replicas(prec):
     torch.cuda.synchronize()
     cP = eng.debug_buffer("P.c").view(n, B, -1).clone()
     xP = eng.debug_buffer("Xpre").view(n, B, -1).clone()
-    tol = 1e-3 if prec == "bf16x3" else 2e-2                     # bf16: rounding ties of stored activations between the R = 5 and R = 1 kernels' tilings
+    tol = 1e-5                     # measured: bit-identical in both modes (the kernels' arithmetic per row does not depend on the replica count)
     ck = Checker(f"batched generator pass, 5 replicas, all-keep dropout ({prec})", tol, metric="max")
     for k in range(n):
         xk = eng.forward(L.ROLE_GENERATOR, z_all[k].contiguous(), patches, patch_pad, text, text_pad, train=True)
