@@ -915,7 +915,9 @@ int cond_forward(Ctx& c, Net& n, const gg_cond* in, CondActs& a, int R, float dr
     // the text tokens carry no dropout: their I2T K / V projection is the same for every replica
     static const bool no_i2t_share = getenv("GG_NO_I2T_SHARE") != nullptr;
     a.i2t_shared = e->xattn && !no_i2t_share && sq_attn_shared_ok(T, E, nh, std::max(1, std::min(R, 3)));
-    const bool share0 = R > 1 && bst && e->wgrad_on && (long)B * S >= 4096;      // (the weight-gradient kernel must engage)
+    // (bf16x3: the split-operand Linear, attention and weight-gradient kernels take the same modulo-indexed operands; GG_NO_SHARE0_X3: A/B)
+    static const bool no_share0_x3 = getenv("GG_NO_SHARE0_X3") != nullptr;
+    const bool share0 = R > 1 && (bst || (use_flash3 && !no_share0_x3)) && e->wgrad_on && (long)B * S >= 4096;      // (the weight-gradient kernel must engage)
     a.share0 = share0;
     const float* x_in = a.x0;
     const float* tok = a.tok;

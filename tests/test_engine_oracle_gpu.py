@@ -31,6 +31,10 @@ CASES = {
     # image-transformer sibling (src/conditional_gan_img_transformer.py): Linear-ReLU-LayerNorm patch encoder, no FiLM
     "img_P40_E256": dict(cfg=img_config(n_genes=70, latent_dims=16, embedding_dims=256, hidden_dims=48, text_dims=20,
                                         patch_dims=72, dropout=0.0), B=4, P=40, T=1),
+    # B * S = 4 112 rows >= 4 096: the dropout replicas share the layer-0 input and its QKV projection (modulo-indexed operands in the
+    # Linear, attention and weight-gradient kernels) - in bf16 mode and, since round 4, in bf16x3
+    "share0_S257_E256": dict(cfg=PathConfig(n_genes=200, latent_dims=32, embedding_dims=256, hidden_dims=64, text_dims=48,
+                                             patch_dims=96, dropout=0.0), B=16, P=256, T=1),
     # smallest shapes: one sample, one patch (S = 2), one text token - every kernel with a one-workgroup grid
     "single_sample": dict(cfg=PathConfig(n_genes=17, latent_dims=8, embedding_dims=32, hidden_dims=16, text_dims=12,
                                           patch_dims=20, dropout=0.0), B=1, P=1, T=1),
@@ -112,7 +116,7 @@ def test_critic_and_generator_iteration_vs_autograd(case):
 
 
 @pytest.mark.usefixtures("parity_mode")
-@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256", "img_P40_E256"])
+@pytest.mark.parametrize("case", ["text_T77_E256", "mid_T5_ragged", "hot_tiles_E256", "film_P33_E256", "img_P40_E256", "share0_S257_E256"])
 def test_replica_stacked_passes_vs_autograd(case):
     """With dropout on, the three critic passes of an iteration run as replicas stacked on the batch axis (two of them
     carry gradient; shared layer inputs, shared text keys, replica-summed gradients).  A drop probability of 1e-7 keeps
