@@ -2647,13 +2647,14 @@ size_t x3_smem(int S, int DH, int ck = X3Chunk<NS>::CK) {
     return (size_t)NS * 4 * ck * (DH + 8) * 2 + Sp + 64 + 16;
 }
 
-template <int DH, int NS>
-__global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int mask_B,
+// CK: keys per LDS chunk.  With CK = 32 the three-part forward kernel's images are 55 KB and its 229 registers leave room for a second
+// workgroup per CU (two waves per SIMD instead of one); launch_bounds' second argument only caps the register budget
+template <int DH, int NS, int CK = X3Chunk<NS>::CK>
+__global__ __launch_bounds__(256, CK == 32 ? 2 : 1) void attn_fwd_x3_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int mask_B,
                                                             float* __restrict__ ctx, float* __restrict__ lse2, int S, int E, int nh,
                                                             DropKey drop_in, int qkv_B, int npairs, int nqg) {
     const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int CK = X3Chunk<NS>::CK;
     const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     constexpr int LDK = DH + 8, IMG = CK * LDK, PART = 4 * IMG;         // part sp: [buf][K | V][IMG]
     __bf16* L0 = reinterpret_cast<__bf16*>(smem_raw);
@@ -3363,18 +3364,22 @@ int flash_attn_fwd_x3(const float* qkv, const uint8_t* mask, int mask_B, float* 
     const int qB = (int)(qkv_B > 0 ? qkv_B : N), dh = E / nh;
     const int nqg = ((S + 31) / 32 + 3) / 4;
     const dim3 grid((unsigned)(((N * nh + 7) / 8) * 8 * nqg));
-#define GG_F3(D, NS_)                                                                                                    \
+#define GG_F3C(D, NS_, CK_)                                                                                              \
     do {                                                                                                               \
-        const size_t sm = x3_smem<NS_>(S, D);                                                                          \
-        GG_TRY(set_smem(&attn_fwd_x3_kernel<D, NS_>, sm));                                                              \
-        hipLaunchKernelGGL((attn_fwd_x3_kernel<D, NS_>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, (int)(N * nh), nqg); \
+        const size_t sm = x3_smem<NS_>(S, D, CK_);                                                                     \
+        GG_TRY(set_smem(&attn_fwd_x3_kernel<D, NS_, CK_>, sm));                                                         \
+        hipLaunchKernelGGL((attn_fwd_x3_kernel<D, NS_, CK_>), grid, dim3(256), sm, st, qkv, mask, mask_B, ctx, lse2, S, E, nh, drop, qB, (int)(N * nh), nqg); \
     } while (0)
+#define GG_F3(D, NS_) GG_F3C(D, NS_, X3Chunk<NS_>::CK)
+    static const bool ck64 = getenv("GG_X3_FWD_CK64") != nullptr;       // A/B: the one-workgroup-per-CU form of the production-width forward kernel
     if (ns == 3) {
-        if (dh == 64) GG_F3(64, 3); else if (dh == 32) GG_F3(32, 3); else GG_F3(16, 3);
+        if (dh == 64 && !ck64) GG_F3C(64, 3, 32);
+        else if (dh == 64) GG_F3(64, 3); else if (dh == 32) GG_F3(32, 3); else GG_F3(16, 3);
     } else {
         if (dh == 64) GG_F3(64, 2); else if (dh == 32) GG_F3(32, 2); else GG_F3(16, 2);
     }
 #undef GG_F3
+#undef GG_F3C
     GG_CHECK_HIP(hipGetLastError());
     return 0;
 }
