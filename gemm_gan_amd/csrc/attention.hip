@@ -2805,15 +2805,16 @@ __global__ __launch_bounds__(256, CK == 32 ? 2 : 1) void attn_fwd_x3_kernel(cons
 }
 
 // dQ: the wave's query tile (Q, dO parts, lse, delta in registers); K and V chunks stream
-template <int DH, int NS>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+// CK / OCC: keys per LDS chunk and workgroups per CU the register budget is cut for (production width, two parts: 64 keys = 74 KB and
+// <= 256 registers put two workgroups on a CU; the default is the one-workgroup form)
+template <int DH, int NS, int CK = X3Chunk<NS>::CK, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                                const float* __restrict__ dctx, const float* __restrict__ lse2,
                                                                float* __restrict__ delta, const uint8_t* __restrict__ mask, int mask_B,
                                                                float* __restrict__ dqkv, int S, int E, int nh, DropKey drop_in, int qkv_B,
                                                                int npairs, int nqg) {
     const DropKey drop = drop_live(drop_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int CK = X3Chunk<NS>::CK;
     const int Sp = (S + 31) / 32 * 32, R = rm_rows(S);
     constexpr int LDK = DH + 8, IMG = CK * LDK, PART = 4 * IMG;
     __bf16* L0 = reinterpret_cast<__bf16*>(smem_raw);
@@ -2956,8 +2957,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const float* __r
 // dK / dV: the wave's key tile (K, V parts in registers); Q and dO chunks with their lse / delta rows stream (64-row chunks)
 template <int NS>
 size_t x3_dkv_smem(int DH) { return (size_t)NS * 4 * 64 * (DH + 8) * 2 + (size_t)4 * 64 * 4; }
-template <int DH, int NS>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+template <int DH, int NS, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                 const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                 const uint8_t* __restrict__ mask, int mask_B, float* __restrict__ dqkv,
                                                                 int S, int E, int nh, DropKey drop_in, int qkv_B, int npairs, int nkg) {
@@ -3399,8 +3400,28 @@ int flash_attn_bwd_x3(const float* qkv, const float* ctx, const float* dctx, con
         GG_TRY(set_smem(&attn_bwd_dkv_x3_kernel<D, NS_>, smk));                                                         \
         hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<D, NS_>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng); \
     } while (0)
+    // bit 0: dQ kernel, bit 1: dK / dV kernel in the two-workgroups-per-CU form (cfg3 bf16x3 step, interleaved: neither 74.6 ms,
+    // dQ only 72.1, dK / dV only 72.0 - its 92 bytes of spills included -, both 69.7); GG_X3_BWD_OCC2=0: the one-workgroup forms
+    static const int occ2 = getenv("GG_X3_BWD_OCC2") ? atoi(getenv("GG_X3_BWD_OCC2")) : 3;
     if (ns == 3) {
         if (dh == 64) GG_B3(64, 3); else if (dh == 32) GG_B3(32, 3); else GG_B3(16, 3);
+    } else if (dh == 64 && occ2) {
+        const size_t sm = (occ2 & 1) ? x3_smem<2>(S, 64, 64) : x3_smem<2>(S, 64), smk = x3_dkv_smem<2>(64);
+        if (occ2 & 1) {
+            GG_TRY(set_smem(&attn_bwd_dq_x3_kernel<64, 2, 64, 2>, sm));
+            hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<64, 2, 64, 2>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng);
+        } else {
+            GG_TRY(set_smem(&attn_bwd_dq_x3_kernel<64, 2>, sm));
+            hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<64, 2>), grid, dim3(256), sm, st, qkv, ctx, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng);
+        }
+        if (ev_mid) GG_CHECK_HIP(hipEventRecord(ev_mid, st));
+        if (occ2 & 2) {
+            GG_TRY(set_smem(&attn_bwd_dkv_x3_kernel<64, 2, 2>, smk));
+            hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<64, 2, 2>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng);
+        } else {
+            GG_TRY(set_smem(&attn_bwd_dkv_x3_kernel<64, 2>, smk));
+            hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<64, 2>), grid, dim3(256), smk, st, qkv, dctx, lse2, delta, mask, mask_B, dqkv, S, E, nh, drop, qB, (int)(N * nh), ng);
+        }
     } else {
         if (dh == 64) GG_B3(64, 2); else if (dh == 32) GG_B3(32, 2); else GG_B3(16, 2);
     }
