@@ -115,22 +115,25 @@ struct XStage {
     }
 };
 
-template <int NT_RES, int NS>
-__global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
+// OCC: workgroups per CU the register budget is cut for - 128-column groups (NT_RES = 4) with <= 256 registers: the two-part kernel has
+// 55 KB of LDS, the three-part one 70 KB with ONE weight buffer (WB = 1: a second barrier per chunk instead of the second image).
+// In that form the column group is the fast grid index, so that the workgroups that read the same token rows run together (L2).
+template <int NT_RES, int NS, int OCC = 1, int WB = 2>
+__global__ __launch_bounds__(256, OCC) void tlin3_kernel(const TlinP p) {
     const DropKey dkey = drop_live(p.drop);
     constexpr int KSL = Slice<NS>::KSL, WLD = Slice<NS>::WLD;
     constexpr int N = 32 * NT_RES;                     // columns of this workgroup's group
     static_assert(KSL == 64, "weight chunk staging: 32 rows x 8 pieces = 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WIMG = 2 * 32 * WLD, XIMG = 4 * 32 * WLD;                 // elements per weight / activation image (one split part)
-    __bf16* const Wsp = reinterpret_cast<__bf16*>(smem_raw);                // [NS][2][32*WLD]
+    constexpr int WIMG = WB * 32 * WLD, XIMG = 4 * 32 * WLD;                // elements per weight / activation image (one split part)
+    __bf16* const Wsp = reinterpret_cast<__bf16*>(smem_raw);                // [NS][WB][32*WLD]
     __bf16* const Xsp = Wsp + NS * WIMG;                                    // [NS][4][32*WLD]
     float* const Ps = reinterpret_cast<float*>(Xsp + NS * XIMG);            // bias | gamma | beta  [3][N]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;
-    const int gcol = (int)blockIdx.y * N;
-    const int tok0 = (int)blockIdx.x * 128 + wave * 32;
+    const int gcol = (int)(OCC == 2 ? blockIdx.x : blockIdx.y) * N;
+    const int tok0 = (int)(OCC == 2 ? blockIdx.y : blockIdx.x) * 128 + wave * 32;
     const int last_tok = (int)p.M - 1;
     const int nks = p.K / KSL;
     const int nchunks = nks * NT_RES;
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 #pragma unroll
         for (int sp = 0; sp < NS; ++sp) wreg[set][sp] = *reinterpret_cast<const u32x4*>(src + (long)sp * p.w_part_stride);
     };
-    auto store_chunk = [&](int set) {
+    auto store_chunk = [&](int set) {        // register set `set` -> weight buffer `set` (WB = 2) / the one buffer (WB = 1)
 #pragma unroll
-        for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x4*>(&Wsp[sp * WIMG + set * 32 * WLD + wrow * WLD + 8 * wpiece]) = wreg[set][sp];
+        for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<u32x4*>(&Wsp[sp * WIMG + (WB == 2 ? set : 0) * 32 * WLD + wrow * WLD + 8 * wpiece]) = wreg[set][sp];
     };
 
     XStage<NS> xst;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             }
-            const __bf16* wb0 = Wsp + buf * 32 * WLD + c * WLD + 8 * h;
+            const __bf16* wb0 = Wsp + (WB == 2 ? buf : 0) * 32 * WLD + c * WLD + 8 * h;
             // the fragments of k-step s + 1 are requested before the MFMAs of k-step s: one exposed LDS round trip per chunk, not per step
             bf16x8 wf[2][NS];
 #pragma unroll
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[1][s], acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], xf[0][s], acc[nt], 0, 0, 0);
             }
+            if constexpr (WB == 1) __syncthreads();      // every wave has read this chunk: the one buffer takes the next
             store_chunk(buf ^ 1);          // (after the last chunk: a buffer nobody reads)
             __syncthreads();
             ++chunk;
@@ -345,21 +349,22 @@ __global__ __launch_bounds__(256, 1) void tlin3_kernel(const TlinP p) {
 
 hipEvent_t g3_ev0 = nullptr, g3_ev1 = nullptr;
 
-template <int NT_RES, int NS>
+template <int NT_RES, int NS, int OCC = 1, int WB = 2>
 int launch3(const TlinP& p, int groups, hipStream_t st) {
-    constexpr size_t smem = (size_t)NS * (2 + 4) * 32 * Slice<NS>::WLD * 2 + (size_t)3 * 32 * NT_RES * 4;
+    constexpr size_t smem = (size_t)NS * (WB + 4) * 32 * Slice<NS>::WLD * 2 + (size_t)3 * 32 * NT_RES * 4;
+    static_assert(OCC == 1 || 2 * smem <= 160 * 1024, "two workgroups per CU");
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin3_kernel<NT_RES, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tlin3_kernel<NT_RES, NS, OCC, WB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    const dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)groups);
+    const dim3 grid = OCC == 2 ? dim3((unsigned)groups, (unsigned)((p.M + 127) / 128)) : dim3((unsigned)((p.M + 127) / 128), (unsigned)groups);
     if (g3_ev0) {
-        hipExtLaunchKernelGGL((tlin3_kernel<NT_RES, NS>), grid, dim3(256), (unsigned)smem, st, g3_ev0, g3_ev1, 0, p);
+        hipExtLaunchKernelGGL((tlin3_kernel<NT_RES, NS, OCC, WB>), grid, dim3(256), (unsigned)smem, st, g3_ev0, g3_ev1, 0, p);
         g3_ev0 = g3_ev1 = nullptr;
     } else {
-        hipLaunchKernelGGL((tlin3_kernel<NT_RES, NS>), grid, dim3(256), smem, st, p);
+        hipLaunchKernelGGL((tlin3_kernel<NT_RES, NS, OCC, WB>), grid, dim3(256), smem, st, p);
     }
     GG_CHECK_HIP(hipGetLastError());
     return 0;
@@ -391,10 +396,18 @@ int tlin3(const TlinP& p, hipStream_t st, int nsplit) {
     if (nsplit == 3) {
         if (p.N == 64) return launch3<2, 3>(p, 1, st);
         if (p.N == 128) return launch3<4, 3>(p, 1, st);
+        // calls without a LayerNorm epilogue (QKV, FFN1, patch / text encoders): 128-column groups, two workgroups per CU, one weight buffer
+        // (cfg3 bf16x3 step, interleaved: 65.8 -> 62.9 ms; 56 bytes of spills included).  GG_TLIN3_FWD_OCC1: the one-workgroup form
+        static const bool occ2f = getenv("GG_TLIN3_FWD_OCC1") == nullptr;
+        if (occ2f && !p.ln_g && (p.M + 127) / 128 <= 65535) return launch3<4, 3, 2, 1>(p, p.N / 128, st);
         return launch3<8, 3>(p, p.N / 256, st);
     }
     if (p.N == 64) return launch3<2, 2>(p, 1, st);
     if (p.N == 128) return launch3<4, 2>(p, 1, st);
+    // calls without a LayerNorm epilogue as 128-column groups, two workgroups per CU (cfg3 bf16x3 step, interleaved: 68.3 -> 66.5 ms);
+    // GG_TLIN3_OCC1: the one-workgroup form
+    static const bool occ2 = getenv("GG_TLIN3_OCC1") == nullptr;
+    if (occ2 && !p.ln_g && (p.M + 127) / 128 <= 65535) return launch3<4, 2, 2>(p, p.N / 128, st);
     return launch3<8, 2>(p, p.N / 256, st);
 }
 
